@@ -1,0 +1,625 @@
+// dpx_api.hip — host side of the C-ABI declared in include/deplex_amd.h.
+// Builds into libdeplex_amd.so with:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../include/deplex_amd.h"
+#include "dpx_kernels.h"
+#include "dpx_regions.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define DPX_HIP(expr)                                                                                      \
+  do {                                                                                                     \
+    hipError_t e_ = (expr);                                                                                \
+    if (e_ != hipSuccess)                                                                                  \
+      return fail(e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice ? DPX_ERR_NO_DEVICE : DPX_ERR_HIP, \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                                      \
+  } while (0)
+
+constexpr size_t kLdsLimit = 160 * 1024 - 512;
+
+}  // namespace
+
+struct dpx_handle_s {
+  dpx_config cfg;  // as stored by the reference: patch_size clamped to min(H, W)
+  int H = 0, W = 0, max_batch = 0, device = 0;
+  dpx::Params prm{};
+  int pcap = 1;
+  bool use_lds = true;
+  size_t lds_bytes = 0;
+  hipStream_t stream = nullptr;       // owned, used by the host-pointer entry points
+  hipStream_t last_stream = nullptr;  // stream of the last launch (for result getters)
+  // scratch
+  dpx_cell* d_cells = nullptr;
+  uint32_t* d_meta = nullptr;
+  uint32_t* d_order = nullptr;
+  uint32_t* d_grow_start = nullptr;
+  float* d_cand = nullptr;
+  dpx_plane* d_planes = nullptr;
+  int32_t* d_cell_labels = nullptr;
+  uint2* d_pairs = nullptr;
+  int32_t* d_merge = nullptr;
+  dpx_frame_stats* d_stats = nullptr;
+  uint8_t* d_gflags = nullptr;
+  uint8_t* d_gowner = nullptr;
+  uint32_t* d_gqueue = nullptr;
+  // staging for the host-pointer API (lazy)
+  void* d_in = nullptr;
+  size_t d_in_bytes = 0;
+  int32_t* d_labels = nullptr;
+  size_t d_labels_bytes = 0;
+  // profiling
+  bool profiling = false;
+  hipEvent_t ev[DPX_K_COUNT + 1] = {};
+  bool ev_valid = false;
+  int last_batch = 0;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(T** p, size_t count) {
+  DPX_HIP(hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T)));
+  return DPX_OK;
+}
+
+void free_all(dpx_handle h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  hipFree(h->d_cells);
+  hipFree(h->d_meta);
+  hipFree(h->d_order);
+  hipFree(h->d_grow_start);
+  hipFree(h->d_cand);
+  hipFree(h->d_planes);
+  hipFree(h->d_cell_labels);
+  hipFree(h->d_pairs);
+  hipFree(h->d_merge);
+  hipFree(h->d_stats);
+  hipFree(h->d_gflags);
+  hipFree(h->d_gowner);
+  hipFree(h->d_gqueue);
+  hipFree(h->d_in);
+  hipFree(h->d_labels);
+  for (auto& e : h->ev)
+    if (e) hipEventDestroy(e);
+  if (h->stream) hipStreamDestroy(h->stream);
+}
+
+template <bool DEPTH>
+void launch_planefit(const dpx::Params& prm, const void* d_in, dpx_cell* d_cells, hipStream_t s) {
+  const long long total = static_cast<long long>(prm.batch) * prm.C;
+  if (total == 0) return;
+  const unsigned blocks = static_cast<unsigned>((total + 255) / 256);
+  switch (prm.sheared ? 0 : prm.P) {
+    case 4: hipLaunchKernelGGL((dpx::k_planefit<4, DEPTH>), dim3(blocks), dim3(256), 0, s, prm, d_in, d_cells); break;
+    case 8: hipLaunchKernelGGL((dpx::k_planefit<8, DEPTH>), dim3(blocks), dim3(256), 0, s, prm, d_in, d_cells); break;
+    case 10: hipLaunchKernelGGL((dpx::k_planefit<10, DEPTH>), dim3(blocks), dim3(256), 0, s, prm, d_in, d_cells); break;
+    case 16: hipLaunchKernelGGL((dpx::k_planefit<16, DEPTH>), dim3(blocks), dim3(256), 0, s, prm, d_in, d_cells); break;
+    default: hipLaunchKernelGGL((dpx::k_planefit<0, DEPTH>), dim3(blocks), dim3(256), 0, s, prm, d_in, d_cells); break;
+  }
+}
+
+int run_pipeline(dpx_handle h, const void* d_in, bool depth, int batch, float fx, float fy, float cx, float cy,
+                 int32_t* d_labels, hipStream_t s) {
+  if (batch < 0 || batch > h->max_batch)
+    return fail(DPX_ERR_ARG, "batch " + std::to_string(batch) + " exceeds max_batch " + std::to_string(h->max_batch));
+  DPX_HIP(hipSetDevice(h->device));
+  h->last_stream = s;
+  h->last_batch = batch;
+  if (batch == 0) return DPX_OK;
+  dpx::Params prm = h->prm;
+  prm.batch = batch;
+  prm.fx = fx; prm.fy = fy; prm.cx = cx; prm.cy = cy;
+  const bool prof = h->profiling;
+  if (prof) DPX_HIP(hipEventRecord(h->ev[0], s));
+  if (prm.C > 0) {
+    if (depth)
+      launch_planefit<true>(prm, d_in, h->d_cells, s);
+    else
+      launch_planefit<false>(prm, d_in, h->d_cells, s);
+  }
+  if (prof) DPX_HIP(hipEventRecord(h->ev[1], s));
+  const long long total = static_cast<long long>(batch) * prm.C;
+  if (total > 0)
+    hipLaunchKernelGGL(dpx::k_cellgraph, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, prm, h->d_cells, h->d_meta);
+  if (prof) DPX_HIP(hipEventRecord(h->ev[2], s));
+  dpx::RegionBufs rb{};
+  rb.cells = h->d_cells; rb.meta = h->d_meta; rb.order = h->d_order; rb.grow_start = h->d_grow_start;
+  rb.cand = h->d_cand; rb.planes = h->d_planes; rb.cell_labels = h->d_cell_labels; rb.pairs = h->d_pairs;
+  rb.merge = h->d_merge; rb.stats = h->d_stats; rb.g_flags = h->d_gflags; rb.g_owner = h->d_gowner;
+  rb.g_queue = h->d_gqueue; rb.pcap = h->pcap;
+  if (h->use_lds)
+    hipLaunchKernelGGL(dpx::k_regions<true>, dim3(batch), dim3(64), h->lds_bytes, s, prm, rb);
+  else
+    hipLaunchKernelGGL(dpx::k_regions<false>, dim3(batch), dim3(64), h->lds_bytes, s, prm, rb);
+  if (prof) DPX_HIP(hipEventRecord(h->ev[3], s));
+  {
+    const long long per_frame = static_cast<long long>(prm.H) * ((prm.W + 3) / 4);
+    const long long tot = per_frame * batch;
+    if (tot > 0)
+      hipLaunchKernelGGL(dpx::k_labels, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s, prm, h->d_cell_labels, d_labels);
+  }
+  if (prof) {
+    DPX_HIP(hipEventRecord(h->ev[4], s));
+    h->ev_valid = true;
+  }
+  DPX_HIP(hipGetLastError());
+  return DPX_OK;
+}
+
+int ensure_staging(dpx_handle h, size_t in_bytes, size_t label_bytes) {
+  if (h->d_in_bytes < in_bytes) {
+    if (h->d_in) hipFree(h->d_in);
+    h->d_in = nullptr;
+    h->d_in_bytes = 0;
+    DPX_HIP(hipMalloc(&h->d_in, in_bytes));
+    h->d_in_bytes = in_bytes;
+  }
+  if (h->d_labels_bytes < label_bytes) {
+    if (h->d_labels) hipFree(h->d_labels);
+    h->d_labels = nullptr;
+    h->d_labels_bytes = 0;
+    DPX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_labels), label_bytes));
+    h->d_labels_bytes = label_bytes;
+  }
+  return DPX_OK;
+}
+
+int host_process(dpx_handle h, const void* in, bool depth, int batch, float fx, float fy, float cx, float cy, int32_t* labels) {
+  if (!h) return fail(DPX_ERR_ARG, "null handle");
+  if (batch < 0 || batch > h->max_batch)
+    return fail(DPX_ERR_ARG, "batch " + std::to_string(batch) + " exceeds max_batch " + std::to_string(h->max_batch));
+  if (batch == 0) return DPX_OK;
+  if (!in || !labels) return fail(DPX_ERR_ARG, "null buffer");
+  DPX_HIP(hipSetDevice(h->device));
+  const size_t N = static_cast<size_t>(h->H) * h->W;
+  const size_t in_bytes = N * batch * (depth ? sizeof(uint16_t) : 3 * sizeof(float));
+  const size_t lab_bytes = N * batch * sizeof(int32_t);
+  int rc = ensure_staging(h, in_bytes, lab_bytes);
+  if (rc) return rc;
+  DPX_HIP(hipMemcpyAsync(h->d_in, in, in_bytes, hipMemcpyHostToDevice, h->stream));
+  rc = run_pipeline(h, h->d_in, depth, batch, fx, fy, cx, cy, h->d_labels, h->stream);
+  if (rc) return rc;
+  DPX_HIP(hipMemcpyAsync(labels, h->d_labels, lab_bytes, hipMemcpyDeviceToHost, h->stream));
+  DPX_HIP(hipStreamSynchronize(h->stream));
+  return DPX_OK;
+}
+
+int sync_last(dpx_handle h) {
+  DPX_HIP(hipSetDevice(h->device));
+  DPX_HIP(hipStreamSynchronize(h->last_stream));
+  return DPX_OK;
+}
+
+// ---- small test kernels ---------------------------------------------------------------------------------
+__global__ void k_test_math(int which, const double* a, const double* b, double* out, long long n) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s, c;
+  switch (which) {
+    case 0: out[i] = dpxm::datan2(a[i], b[i]); break;
+    case 1: dpxm::sincos_small(a[i], &s, &c); out[i] = s; break;
+    case 2: dpxm::sincos_small(a[i], &s, &c); out[i] = c; break;
+    case 3: out[i] = dpxm::dacos(a[i]); break;
+    default: out[i] = dpxm::dsqrt(a[i]); break;
+  }
+}
+
+__global__ void k_test_eig3(const double* A, double* Q, double* w, int* rc, long long n) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  dpx::Sym3 S{A[6 * i], A[6 * i + 1], A[6 * i + 2], A[6 * i + 3], A[6 * i + 4], A[6 * i + 5]};
+  dpx::Eig3 e;
+  dpx::eig3_hybrid(S, e);
+  double* q = Q + 9 * i;
+  q[0] = e.q00; q[1] = e.q01; q[2] = e.q02; q[3] = e.q10; q[4] = e.q11; q[5] = e.q12; q[6] = e.q20; q[7] = e.q21; q[8] = e.q22;
+  w[3 * i] = e.w0; w[3 * i + 1] = e.w1; w[3 * i + 2] = e.w2;
+  rc[i] = e.path;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dpx_version(void) { return "deplex_amd 0.1 (gfx950)"; }
+
+const char* dpx_last_error(void) { return g_err.c_str(); }
+
+void dpx_default_config(dpx_config* c) {
+  if (!c) return;
+  c->patch_size = 10;
+  c->histogram_bins_per_coord = 20;
+  c->min_cos_angle_merge = 0.90f;
+  c->max_merge_dist = 500.f;
+  c->min_region_growing_candidate_size = 5;
+  c->min_region_growing_cells_activated = 4;
+  c->min_region_planarity_score = 0.55f;
+  c->depth_sigma_coeff = 1.425e-6f;
+  c->depth_sigma_margin = 10.f;
+  c->min_pts_per_cell = 3;
+  c->depth_discontinuity_threshold = 160.f;
+  c->max_number_depth_discontinuity = 1;
+  c->ransac_refinement = 0;
+  c->ransac_max_iterations = 1000;
+  c->ransac_threshold = 1.f;
+  c->ransac_inliers_ratio = 0.9f;
+}
+
+int dpx_config_from_ini(const char* path, dpx_config* cfg) {
+  if (!path || !cfg) return fail(DPX_ERR_ARG, "null argument");
+  dpx_default_config(cfg);
+  std::ifstream ini(path);
+  if (!ini.is_open()) return fail(DPX_ERR_IO, std::string("Couldn't open ini file: ") + path);
+  try {
+    while (ini) {
+      std::string line;
+      std::getline(ini, line);
+      if (line.empty() || line[0] == '#') continue;
+      const size_t eq = line.find_first_of('=');
+      if (eq == std::string::npos || eq == 0) continue;
+      const std::string key = line.substr(0, eq), value = line.substr(eq + 1);
+      if (key == "patchSize") cfg->patch_size = std::stoi(value);
+      else if (key == "histogramBinsPerCoord") cfg->histogram_bins_per_coord = std::stoi(value);
+      else if (key == "minCosAngleForMerge") cfg->min_cos_angle_merge = std::stof(value);
+      else if (key == "maxMergeDist") cfg->max_merge_dist = std::stof(value);
+      else if (key == "minRegionGrowingCandidateSize") cfg->min_region_growing_candidate_size = std::stoi(value);
+      else if (key == "minRegionGrowingCellsActivated") cfg->min_region_growing_cells_activated = std::stoi(value);
+      else if (key == "minRegionPlanarityScore") cfg->min_region_planarity_score = std::stof(value);
+      else if (key == "depthSigmaCoeff") cfg->depth_sigma_coeff = std::stof(value);
+      else if (key == "depthSigmaMargin") cfg->depth_sigma_margin = std::stof(value);
+      else if (key == "minPtsPerCell") cfg->min_pts_per_cell = std::stoi(value);
+      else if (key == "depthDiscontinuityThreshold") cfg->depth_discontinuity_threshold = std::stof(value);
+      else if (key == "maxNumberDepthDiscontinuity") cfg->max_number_depth_discontinuity = std::stoi(value);
+      else if (key == "ransacRefinement") cfg->ransac_refinement = static_cast<bool>(std::stoi(value)) ? 1 : 0;
+      else if (key == "ransacMaxIterations") cfg->ransac_max_iterations = std::stoi(value);
+      else if (key == "ransacThreshold") cfg->ransac_threshold = std::stof(value);
+      else if (key == "ransacInliersRatio") cfg->ransac_inliers_ratio = std::stof(value);
+      else std::fprintf(stderr, "Unknown parameter name: %s\n", key.c_str());
+    }
+  } catch (const std::exception& e) {
+    return fail(DPX_ERR_ARG, std::string("invalid value in ini file: ") + e.what());
+  }
+  return DPX_OK;
+}
+
+int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width, int32_t max_batch, int32_t device,
+               dpx_handle* out) {
+  if (!cfg || !out) return fail(DPX_ERR_ARG, "null argument");
+  *out = nullptr;
+  // plane_extractor.cpp:161-164
+  if (cfg->patch_size == 0)
+    return fail(DPX_ERR_PATCH_ZERO, "Error! Invalid config parameter: patchSize(" + std::to_string(cfg->patch_size) +
+                                        "). patchSize has to be positive.");
+  if (cfg->patch_size < 0 || cfg->min_pts_per_cell == 0 || cfg->histogram_bins_per_coord < 1 || image_height < 0 ||
+      image_width < 0)
+    return fail(DPX_ERR_UNDEFINED,
+                "configuration undefined in the reference (negative patchSize, minPtsPerCell==0 or histogramBinsPerCoord<1)");
+  if (cfg->ransac_refinement)
+    return fail(DPX_ERR_UNDEFINED, "ransac_refinement is not implemented yet in this build");
+  if (max_batch < 1) return fail(DPX_ERR_ARG, "max_batch must be >= 1");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) return fail(DPX_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(DPX_ERR_NO_DEVICE, "HIP device index out of range");
+  DPX_HIP(hipSetDevice(device));
+
+  dpx_handle h = new dpx_handle_s();
+  h->cfg = *cfg;
+  h->H = image_height;
+  h->W = image_width;
+  h->max_batch = max_batch;
+  h->device = device;
+  // plane_extractor.cpp:155-160
+  const int nh = image_width / std::max(cfg->patch_size, 1);
+  const int nv = image_height / std::max(cfg->patch_size, 1);
+  h->cfg.patch_size = std::min(cfg->patch_size, std::min(image_height, image_width));
+  dpx::Params& p = h->prm;
+  p.H = image_height; p.W = image_width; p.P = h->cfg.patch_size; p.nh = nh; p.nv = nv;
+  p.C = nh * nv;
+  p.N = image_height * image_width;
+  p.n = p.P * p.P;
+  p.stride_w = nh * p.P;
+  p.sheared = (p.stride_w != image_width) ? 1 : 0;
+  p.batch = 0;
+  p.fx = p.fy = 1.f; p.cx = p.cy = 0.f;
+  p.min_cos = cfg->min_cos_angle_merge;
+  p.max_merge_dist = cfg->max_merge_dist;
+  p.min_score = cfg->min_region_planarity_score;
+  p.sigma_coeff = cfg->depth_sigma_coeff;
+  p.sigma_margin = cfg->depth_sigma_margin;
+  p.disc_thr = cfg->depth_discontinuity_threshold;
+  p.tol_sin = sqrtf(1.0f - cfg->min_cos_angle_merge * cfg->min_cos_angle_merge);  // cell_segment.cpp:106
+  p.hist_B = cfg->histogram_bins_per_coord;
+  p.min_cand = cfg->min_region_growing_candidate_size;
+  p.min_cells = cfg->min_region_growing_cells_activated;
+  p.max_disc = cfg->max_number_depth_discontinuity;
+  p.valid_thr = (3ll * p.n) / cfg->min_pts_per_cell;  // cell_segment.cpp:23
+  if (p.P == 0) {  // zero-sized image: no cells
+    p.P = 1;
+    p.n = 1;
+  }
+  const long long nb = static_cast<long long>(p.hist_B) * p.hist_B;
+  const size_t hist_bytes = static_cast<size_t>(3 * nb + 1) * 4;
+  if (hist_bytes > 64 * 1024) {
+    delete h;
+    return fail(DPX_ERR_CAPACITY, "histogramBinsPerCoord too large for the on-chip histogram (max 73)");
+  }
+  const size_t C = static_cast<size_t>(p.C);
+  const size_t lds_state = hist_bytes + 6 * C + 16;
+  const char* force = std::getenv("DPX_FORCE_GLOBAL_STATE");
+  h->use_lds = lds_state <= kLdsLimit && !(force && force[0] == '1');
+  h->lds_bytes = h->use_lds ? lds_state : hist_bytes + 16;
+  h->pcap = static_cast<int>(std::max<long long>(1, cfg->min_region_growing_cells_activated <= 1
+                                                      ? static_cast<long long>(C)
+                                                      : static_cast<long long>(C) / cfg->min_region_growing_cells_activated));
+  const size_t B = static_cast<size_t>(max_batch);
+  int rc = DPX_OK;
+  auto A = [&](int r) { if (rc == DPX_OK) rc = r; };
+  A(dev_alloc(&h->d_cells, B * C));
+  A(dev_alloc(&h->d_meta, B * C));
+  A(dev_alloc(&h->d_order, B * C));
+  A(dev_alloc(&h->d_grow_start, B * (C + 1)));
+  A(dev_alloc(&h->d_cand, B * h->pcap * 12));
+  A(dev_alloc(&h->d_planes, B * h->pcap));
+  A(dev_alloc(&h->d_cell_labels, B * C));
+  A(dev_alloc(&h->d_pairs, B * 2 * C));
+  A(dev_alloc(&h->d_merge, B * h->pcap));
+  A(dev_alloc(&h->d_stats, B));
+  if (!h->use_lds) {
+    A(dev_alloc(&h->d_gflags, B * C));
+    A(dev_alloc(&h->d_gowner, B * C));
+    A(dev_alloc(&h->d_gqueue, B * C));
+  }
+  if (rc == DPX_OK && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
+    rc = fail(DPX_ERR_HIP, "hipStreamCreate failed");
+  for (auto& ev : h->ev)
+    if (rc == DPX_OK && hipEventCreate(&ev) != hipSuccess) rc = fail(DPX_ERR_HIP, "hipEventCreate failed");
+  if (rc == DPX_OK && h->lds_bytes > 48 * 1024) {
+    hipError_t e2 = h->use_lds ? hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions<true>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds_bytes))
+                               : hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions<false>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds_bytes));
+    if (e2 != hipSuccess) rc = fail(DPX_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e2));
+  }
+  if (rc != DPX_OK) {
+    const std::string keep = g_err;
+    free_all(h);
+    delete h;
+    g_err = keep;
+    return rc;
+  }
+  h->last_stream = h->stream;
+  *out = h;
+  return DPX_OK;
+}
+
+void dpx_destroy(dpx_handle h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  free_all(h);
+  delete h;
+}
+
+int dpx_process_pcd(dpx_handle h, const float* xyz, int64_t n_points, int32_t* labels) {
+  if (!h) return fail(DPX_ERR_ARG, "null handle");
+  // plane_extractor.cpp:188-194
+  if (n_points != static_cast<int64_t>(h->W) * h->H)
+    return fail(DPX_ERR_SHAPE, "Error! Number of points doesn't match image shape: " + std::to_string(n_points) +
+                                   " != " + std::to_string(h->H) + " x " + std::to_string(h->W));
+  if (n_points == 0) return DPX_OK;
+  return host_process(h, xyz, false, 1, 1.f, 1.f, 0.f, 0.f, labels);
+}
+
+int dpx_process_pcd_batch(dpx_handle h, const float* xyz, int32_t batch, int32_t* labels) {
+  return host_process(h, xyz, false, batch, 1.f, 1.f, 0.f, 0.f, labels);
+}
+
+int dpx_process_depth_batch(dpx_handle h, const uint16_t* depth, int32_t batch, float fx, float fy, float cx, float cy,
+                            int32_t* labels) {
+  return host_process(h, depth, true, batch, fx, fy, cx, cy, labels);
+}
+
+int dpx_process_depth_batch_device(dpx_handle h, const void* d_depth, int32_t batch, float fx, float fy, float cx,
+                                   float cy, void* d_labels, void* hip_stream) {
+  if (!h) return fail(DPX_ERR_ARG, "null handle");
+  if (batch > 0 && (!d_depth || !d_labels)) return fail(DPX_ERR_ARG, "null buffer");
+  return run_pipeline(h, d_depth, true, batch, fx, fy, cx, cy, static_cast<int32_t*>(d_labels), static_cast<hipStream_t>(hip_stream));
+}
+
+int dpx_process_pcd_batch_device(dpx_handle h, const void* d_xyz, int32_t batch, void* d_labels, void* hip_stream) {
+  if (!h) return fail(DPX_ERR_ARG, "null handle");
+  if (batch > 0 && (!d_xyz || !d_labels)) return fail(DPX_ERR_ARG, "null buffer");
+  return run_pipeline(h, d_xyz, false, batch, 1.f, 1.f, 0.f, 0.f, static_cast<int32_t*>(d_labels), static_cast<hipStream_t>(hip_stream));
+}
+
+int dpx_backproject(const uint16_t* depth, int32_t height, int32_t width, float fx, float fy, float cx, float cy,
+                    float* xyz, int32_t device) {
+  if (height < 0 || width < 0) return fail(DPX_ERR_ARG, "negative image size");
+  const size_t N = static_cast<size_t>(height) * width;
+  if (N == 0) return DPX_OK;
+  if (!depth || !xyz) return fail(DPX_ERR_ARG, "null buffer");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(DPX_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+  DPX_HIP(hipSetDevice(device));
+  uint16_t* d_d = nullptr;
+  float* d_x = nullptr;
+  DPX_HIP(hipMalloc(reinterpret_cast<void**>(&d_d), N * 2));
+  if (hipMalloc(reinterpret_cast<void**>(&d_x), N * 12) != hipSuccess) {
+    hipFree(d_d);
+    return fail(DPX_ERR_HIP, "hipMalloc failed");
+  }
+  hipError_t e = hipMemcpy(d_d, depth, N * 2, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(dpx::k_backproject, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, 0, d_d, height, width, fx, fy, cx, cy, d_x);
+    e = hipMemcpy(xyz, d_x, N * 12, hipMemcpyDeviceToHost);
+  }
+  hipFree(d_d);
+  hipFree(d_x);
+  if (e != hipSuccess) return fail(DPX_ERR_HIP, hipGetErrorString(e));
+  return DPX_OK;
+}
+
+int dpx_grid_dims(dpx_handle h, int32_t* nh, int32_t* nv) {
+  if (!h) return fail(DPX_ERR_ARG, "null handle");
+  if (nh) *nh = h->prm.nh;
+  if (nv) *nv = h->prm.nv;
+  return DPX_OK;
+}
+
+#define DPX_CHECK_FRAME()                                                            \
+  if (!h || !out) return fail(DPX_ERR_ARG, "null argument");                         \
+  if (frame < 0 || frame >= h->last_batch) return fail(DPX_ERR_ARG, "frame index out of range of the last call"); \
+  {                                                                                  \
+    int rc_ = sync_last(h);                                                          \
+    if (rc_) return rc_;                                                             \
+  }
+
+int dpx_get_cells(dpx_handle h, int32_t frame, dpx_cell* out) {
+  DPX_CHECK_FRAME();
+  const size_t C = h->prm.C;
+  if (C) DPX_HIP(hipMemcpy(out, h->d_cells + frame * C, C * sizeof(dpx_cell), hipMemcpyDeviceToHost));
+  return DPX_OK;
+}
+
+int dpx_get_cell_edges(dpx_handle h, int32_t frame, uint8_t* out) {
+  DPX_CHECK_FRAME();
+  const size_t C = h->prm.C;
+  std::vector<uint32_t> tmp(C);
+  if (C) DPX_HIP(hipMemcpy(tmp.data(), h->d_meta + frame * C, C * 4, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < C; ++i) out[i] = static_cast<uint8_t>(tmp[i] & 0xFF);
+  return DPX_OK;
+}
+
+int dpx_get_cell_labels(dpx_handle h, int32_t frame, int32_t* out) {
+  DPX_CHECK_FRAME();
+  const size_t C = h->prm.C;
+  if (C) DPX_HIP(hipMemcpy(out, h->d_cell_labels + frame * C, C * 4, hipMemcpyDeviceToHost));
+  return DPX_OK;
+}
+
+int dpx_get_frame_stats(dpx_handle h, int32_t frame, dpx_frame_stats* out) {
+  DPX_CHECK_FRAME();
+  DPX_HIP(hipMemcpy(out, h->d_stats + frame, sizeof(dpx_frame_stats), hipMemcpyDeviceToHost));
+  return DPX_OK;
+}
+
+int dpx_get_planes(dpx_handle h, int32_t frame, dpx_plane* out, int32_t cap, int32_t* n_out) {
+  if (!n_out) return fail(DPX_ERR_ARG, "null argument");
+  dpx_frame_stats st;
+  int rc = dpx_get_frame_stats(h, frame, &st);
+  if (rc) return rc;
+  *n_out = st.segments;
+  const int n = std::min(st.segments, cap);
+  if (n > 0 && out)
+    DPX_HIP(hipMemcpy(out, h->d_planes + static_cast<size_t>(frame) * h->pcap, n * sizeof(dpx_plane), hipMemcpyDeviceToHost));
+  return DPX_OK;
+}
+
+int dpx_set_profiling(dpx_handle h, int32_t enable) {
+  if (!h) return fail(DPX_ERR_ARG, "null handle");
+  h->profiling = enable != 0;
+  h->ev_valid = false;
+  return DPX_OK;
+}
+
+int dpx_get_kernel_ms(dpx_handle h, float* ms) {
+  if (!h || !ms) return fail(DPX_ERR_ARG, "null argument");
+  if (!h->ev_valid) return fail(DPX_ERR_ARG, "no profiled call recorded");
+  DPX_HIP(hipSetDevice(h->device));
+  DPX_HIP(hipEventSynchronize(h->ev[DPX_K_COUNT]));
+  for (int k = 0; k < DPX_K_COUNT; ++k) DPX_HIP(hipEventElapsedTime(&ms[k], h->ev[k], h->ev[k + 1]));
+  return DPX_OK;
+}
+
+int dpx_time_planefit(dpx_handle h, const void* d_in, int32_t input_kind, int32_t batch, float fx, float fy, float cx,
+                      float cy, int32_t iters, void* hip_stream, float* avg_ms) {
+  if (!h || !d_in || !avg_ms || iters < 1) return fail(DPX_ERR_ARG, "bad argument");
+  if (batch < 1 || batch > h->max_batch) return fail(DPX_ERR_ARG, "batch out of range");
+  DPX_HIP(hipSetDevice(h->device));
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  dpx::Params prm = h->prm;
+  prm.batch = batch;
+  prm.fx = fx; prm.fy = fy; prm.cx = cx; prm.cy = cy;
+  hipEvent_t a, b;
+  DPX_HIP(hipEventCreate(&a));
+  DPX_HIP(hipEventCreate(&b));
+  DPX_HIP(hipEventRecord(a, s));
+  for (int i = 0; i < iters; ++i) {
+    if (input_kind == 0)
+      launch_planefit<true>(prm, d_in, h->d_cells, s);
+    else
+      launch_planefit<false>(prm, d_in, h->d_cells, s);
+  }
+  DPX_HIP(hipEventRecord(b, s));
+  DPX_HIP(hipEventSynchronize(b));
+  float ms = 0.f;
+  DPX_HIP(hipEventElapsedTime(&ms, a, b));
+  hipEventDestroy(a);
+  hipEventDestroy(b);
+  *avg_ms = ms / iters;
+  return DPX_OK;
+}
+
+int64_t dpx_planefit_bytes(dpx_handle h, int32_t input_kind, int32_t batch) {
+  if (!h) return 0;
+  const int64_t N = static_cast<int64_t>(h->H) * h->W;
+  return static_cast<int64_t>(batch) * (N * (input_kind == 0 ? 2 : 12) + static_cast<int64_t>(h->prm.C) * sizeof(dpx_cell));
+}
+
+int dpx_test_math(int32_t which, const double* a, const double* b, double* out, int64_t n, int32_t device) {
+  if (n <= 0) return DPX_OK;
+  DPX_HIP(hipSetDevice(device));
+  double *da = nullptr, *db = nullptr, *dout = nullptr;
+  DPX_HIP(hipMalloc(reinterpret_cast<void**>(&da), n * 8));
+  DPX_HIP(hipMalloc(reinterpret_cast<void**>(&db), n * 8));
+  DPX_HIP(hipMalloc(reinterpret_cast<void**>(&dout), n * 8));
+  DPX_HIP(hipMemcpy(da, a, n * 8, hipMemcpyHostToDevice));
+  DPX_HIP(hipMemcpy(db, b ? b : a, n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_test_math, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, 0, which, da, db, dout, static_cast<long long>(n));
+  DPX_HIP(hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost));
+  hipFree(da);
+  hipFree(db);
+  hipFree(dout);
+  return DPX_OK;
+}
+
+int dpx_test_eig3(const double* A, double* Q, double* w, int32_t* rc, int64_t n, int32_t device) {
+  if (n <= 0) return DPX_OK;
+  DPX_HIP(hipSetDevice(device));
+  double *dA = nullptr, *dQ = nullptr, *dw = nullptr;
+  int* drc = nullptr;
+  DPX_HIP(hipMalloc(reinterpret_cast<void**>(&dA), n * 48));
+  DPX_HIP(hipMalloc(reinterpret_cast<void**>(&dQ), n * 72));
+  DPX_HIP(hipMalloc(reinterpret_cast<void**>(&dw), n * 24));
+  DPX_HIP(hipMalloc(reinterpret_cast<void**>(&drc), n * 4));
+  DPX_HIP(hipMemcpy(dA, A, n * 48, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_test_eig3, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, 0, dA, dQ, dw, drc, static_cast<long long>(n));
+  DPX_HIP(hipMemcpy(Q, dQ, n * 72, hipMemcpyDeviceToHost));
+  DPX_HIP(hipMemcpy(w, dw, n * 24, hipMemcpyDeviceToHost));
+  DPX_HIP(hipMemcpy(rc, drc, n * 4, hipMemcpyDeviceToHost));
+  hipFree(dA);
+  hipFree(dQ);
+  hipFree(dw);
+  hipFree(drc);
+  return DPX_OK;
+}
+
+}  // extern "C"

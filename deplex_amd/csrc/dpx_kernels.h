@@ -1,0 +1,432 @@
+// dpx_kernels.h — HIP kernels of the depth-plane extractor (gfx950 / CDNA4, wave64).
+//
+//   k_planefit   K1+K2  depth (or organised cloud) -> per-cell moments, validity, 3x3 eigen plane fit,
+//                       planarity, merge tolerance, histogram bin.  One 64-byte dpx_cell per cell.
+//   k_cellgraph  K3     per-cell directed 4-neighbour edge bits of the region-growing predicate.
+//   k_regions    K4+K5  (dpx_regions.h) histogram seeding, FIFO region growing, segment fits, merging.
+//   k_labels     K6     cell labels -> per-pixel int32 label map.
+//
+// Reference files restated: utils/depth_image.cpp:55-78, cell_grid.cpp:21-44,69-83, cell_segment.cpp:21-110,
+// cell_segment_stat.cpp:27-81, normals_histogram.cpp:21-49, plane_extractor.cpp:349-392,455-470.
+// Float semantics: every f32 product and sum is rounded separately (compile with -ffp-contract=off); the
+// summation orders are those of the reference's canonical build.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/deplex_amd.h"
+#include "dpx_fit.h"
+
+namespace dpx {
+
+struct Params {
+  int H, W, P, nh, nv, C, N;  // image, patch, grid, cells per frame, pixels per frame
+  int n;                      // points per cell = P*P
+  int stride_w;               // nh*P: the row stride CellGrid::cellContinuousOrganize uses (cell_grid.cpp:71)
+  int sheared;                // stride_w != W
+  int batch;
+  float fx, fy, cx, cy;
+  float min_cos, max_merge_dist, min_score, sigma_coeff, sigma_margin, disc_thr, tol_sin;
+  int hist_B, min_cand, min_cells, max_disc;
+  long long valid_thr;  // (3n)/min_pts_per_cell as the reference's size_t comparison sees it; <0 => never valid
+};
+
+constexpr uint32_t CELL_VALID = 1u, CELL_PLANAR = 2u, CELL_QL = 4u;
+// cell meta byte (k_cellgraph output / region-growing flags)
+constexpr uint32_t F_UNASSIGNED = 1u;          // planar and not yet grown
+constexpr uint32_t F_EDGE0 = 4u;               // bits 2..5: edge to U, D, L, R neighbour passes the predicate
+
+// ------------------------------------------------------------------------------------------------------
+// Point access.  Cloud index q of cell point (i, j) is (cr*P+i)*stride_w + cc*P + j (cell_grid.cpp:74-80),
+// which is pixel (q / W, q % W) of the organised cloud.
+template <bool DEPTH>
+struct PointSrc {
+  const void* base;  // frame base pointer
+  int W;
+  float fx, fy, cx, cy;
+  int sheared;
+  __device__ __forceinline__ void get(long long q, int row, int col, float& x, float& y, float& z) const {
+    if (DEPTH) {
+      const uint16_t* d = static_cast<const uint16_t*>(base);
+      if (sheared) {
+        row = static_cast<int>(q / W);
+        col = static_cast<int>(q - static_cast<long long>(row) * W);
+      }
+      z = static_cast<float>(d[q]);
+      // depth_image.cpp:71-73: (col - cx) * z / fx, float32, product rounded before the IEEE divide
+      x = ((static_cast<float>(col) - cx) * z) / fx;
+      y = ((static_cast<float>(row) - cy) * z) / fy;
+    } else {
+      const float* p = static_cast<const float*>(base) + 3 * q;
+      x = p[0];
+      y = p[1];
+      z = p[2];
+    }
+  }
+  __device__ __forceinline__ float getz(long long q) const {
+    if (DEPTH) return static_cast<float>(static_cast<const uint16_t*>(base)[q]);
+    return static_cast<const float*>(base)[3 * q + 2];
+  }
+};
+
+// Eigen's linear-vectorised column sum for a column whose first 16-byte-aligned element is index `a`
+// (redux_impl<..., LinearVectorizedTraversal, NoUnrolling> with 4-float packets).
+// fetch(k) returns element k.  Used only when n % 4 != 0 (odd patch sizes); the common case is fused below.
+template <class F>
+__device__ float eigen_colsum_generic(F fetch, int n, int a) {
+  if (a > n) a = n;
+  const int A = ((n - a) / 4) * 4;
+  const int A2 = ((n - a) / 8) * 8;
+  if (A == 0) {
+    float r = fetch(0);
+    for (int i = 1; i < n; ++i) r = r + fetch(i);
+    return r;
+  }
+  float p00 = fetch(a), p01 = fetch(a + 1), p02 = fetch(a + 2), p03 = fetch(a + 3);
+  if (A > 4) {
+    float p10 = fetch(a + 4), p11 = fetch(a + 5), p12 = fetch(a + 6), p13 = fetch(a + 7);
+    for (int i = a + 8; i < a + A2; i += 8) {
+      p00 = p00 + fetch(i);
+      p01 = p01 + fetch(i + 1);
+      p02 = p02 + fetch(i + 2);
+      p03 = p03 + fetch(i + 3);
+      p10 = p10 + fetch(i + 4);
+      p11 = p11 + fetch(i + 5);
+      p12 = p12 + fetch(i + 6);
+      p13 = p13 + fetch(i + 7);
+    }
+    p00 = p00 + p10;
+    p01 = p01 + p11;
+    p02 = p02 + p12;
+    p03 = p03 + p13;
+    if (A > A2) {
+      p00 = p00 + fetch(a + A2);
+      p01 = p01 + fetch(a + A2 + 1);
+      p02 = p02 + fetch(a + A2 + 2);
+      p03 = p03 + fetch(a + A2 + 3);
+    }
+  }
+  float r = (p00 + p02) + (p01 + p03);
+  for (int i = 0; i < a; ++i) r = r + fetch(i);
+  for (int i = a + A; i < n; ++i) r = r + fetch(i);
+  return r;
+}
+
+// Packed 8-chain accumulator for the a == 0 case (n % 4 == 0): element k goes to chain k & 7 while k < A2,
+// the chains are folded pairwise when the 8-wide part ends, a trailing 4-packet is added, then the SSE
+// horizontal add (p0+p2)+(p1+p3).
+struct ColSum8 {
+  float c[8];
+  __device__ __forceinline__ void add(int k, int A2, float v) {
+    if (k < A2) {
+      if (k < 8)
+        c[k & 7] = v;
+      else
+        c[k & 7] = c[k & 7] + v;
+    } else {
+      const int idx = k - A2;  // 0..3: trailing packet
+      if (A2 == 0) {
+        c[idx] = v;
+      } else {
+        if (idx == 0) fold();
+        c[idx] = c[idx] + v;
+      }
+    }
+  }
+  __device__ __forceinline__ void fold() {
+    c[0] = c[0] + c[4];
+    c[1] = c[1] + c[5];
+    c[2] = c[2] + c[6];
+    c[3] = c[3] + c[7];
+  }
+  __device__ __forceinline__ float finish(int n, int A2) {
+    if (A2 > 0 && n == A2) fold();
+    return (c[0] + c[2]) + (c[1] + c[3]);
+  }
+};
+
+// One cell: everything CellSegment::CellSegment does (cell_segment.cpp:21-35) plus the histogram bin.
+template <int PT, bool DEPTH>
+__device__ __forceinline__ void planefit_cell(const Params& prm, const PointSrc<DEPTH>& src, int cr, int cc,
+                                               dpx_cell& out) {
+  const int P = PT ? PT : prm.P;
+  const int n = P * P;
+  const long long q0 = static_cast<long long>(cr) * P * prm.stride_w + static_cast<long long>(cc) * P;
+  const int row0 = cr * P, col0 = cc * P;
+
+  // ---- validity: hasValidPoints + isDepthContinuous (cell_segment.cpp:57-97)
+  bool cont;
+  {
+    // horizontal: k = n/2 .. n/2+P-1
+    const int mid = n / 2;
+    int disc = 0;
+    float prev = src.getz(q0 + static_cast<long long>(mid / P) * prm.stride_w + (mid % P));
+    for (int t = 0; t < P; ++t) {
+      const int k = mid + t;
+      const float cur = src.getz(q0 + static_cast<long long>(k / P) * prm.stride_w + (k % P));
+      if (cur > 0 && __builtin_fabsf(cur - prev) < prm.disc_thr)
+        prev = cur;
+      else if (cur > 0)
+        ++disc;
+    }
+    cont = disc < prm.max_disc;
+    // vertical: k = P/2 + t*P
+    disc = 0;
+    prev = src.getz(q0 + (P / 2));
+    for (int t = 0; t < P; ++t) {
+      const float cur = src.getz(q0 + static_cast<long long>(t) * prm.stride_w + (P / 2));
+      if (cur > 0 && __builtin_fabsf(cur - prev) < prm.disc_thr)
+        prev = cur;
+      else if (cur > 0)
+        ++disc;
+    }
+    cont = cont && (disc < prm.max_disc);
+  }
+
+  // ---- moments (cell_segment_stat.cpp:29-33)
+  float sum[3], pp[6];
+  float fx0 = 0, fy0 = 0, fz0 = 0, lx = 0, ly = 0, lz = 0;  // first and last point
+  int valid_pts = 0;
+  const bool gemm = (n + 6) >= 20;  // Eigen GEMM vs lazy product threshold
+  if ((n & 3) == 0) {
+    const int A2 = (n / 8) * 8;
+    ColSum8 sx, sy, sz;
+    float xx = 0.f, xy = 0.f, xz = 0.f, yy = 0.f, yz = 0.f, zz = 0.f;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        const int k = i * P + j;
+        float x, y, z;
+        src.get(q0 + static_cast<long long>(i) * prm.stride_w + j, row0 + i, col0 + j, x, y, z);
+        valid_pts += z > 0;
+        if (k == 0) {
+          fx0 = x;
+          fy0 = y;
+          fz0 = z;
+        }
+        if (k == n - 1) {
+          lx = x;
+          ly = y;
+          lz = z;
+        }
+        sx.add(k, A2, x);
+        sy.add(k, A2, y);
+        sz.add(k, A2, z);
+        if (gemm || k > 0) {
+          xx = x * x + xx;
+          xy = x * y + xy;
+          xz = x * z + xz;
+          yy = y * y + yy;
+          yz = y * z + yz;
+          zz = z * z + zz;
+        } else {
+          xx = x * x;
+          xy = x * y;
+          xz = x * z;
+          yy = y * y;
+          yz = y * z;
+          zz = z * z;
+        }
+      }
+    }
+    sum[0] = sx.finish(n, A2);
+    sum[1] = sy.finish(n, A2);
+    sum[2] = sz.finish(n, A2);
+    pp[0] = xx; pp[1] = xy; pp[2] = xz; pp[3] = yy; pp[4] = yz; pp[5] = zz;
+  } else {
+    // odd patch sizes: column j of the reference's temporary starts j*n floats past a 16-byte boundary
+    auto fx_ = [&](int k) { float x, y, z; const int i = k / P, j = k - i * P; src.get(q0 + static_cast<long long>(i) * prm.stride_w + j, row0 + i, col0 + j, x, y, z); return x; };
+    auto fy_ = [&](int k) { float x, y, z; const int i = k / P, j = k - i * P; src.get(q0 + static_cast<long long>(i) * prm.stride_w + j, row0 + i, col0 + j, x, y, z); return y; };
+    auto fz_ = [&](int k) { float x, y, z; const int i = k / P, j = k - i * P; src.get(q0 + static_cast<long long>(i) * prm.stride_w + j, row0 + i, col0 + j, x, y, z); return z; };
+    sum[0] = eigen_colsum_generic(fx_, n, 0);
+    sum[1] = eigen_colsum_generic(fy_, n, (4 - (n % 4)) % 4);
+    sum[2] = eigen_colsum_generic(fz_, n, (4 - ((2 * n) % 4)) % 4);
+    float xx = 0.f, xy = 0.f, xz = 0.f, yy = 0.f, yz = 0.f, zz = 0.f;
+    for (int k = 0; k < n; ++k) {
+      const int i = k / P, j = k - i * P;
+      float x, y, z;
+      src.get(q0 + static_cast<long long>(i) * prm.stride_w + j, row0 + i, col0 + j, x, y, z);
+      valid_pts += z > 0;
+      if (k == 0) { fx0 = x; fy0 = y; fz0 = z; }
+      if (k == n - 1) { lx = x; ly = y; lz = z; }
+      if (gemm || k > 0) {
+        xx = x * x + xx; xy = x * y + xy; xz = x * z + xz; yy = y * y + yy; yz = y * z + yz; zz = z * z + zz;
+      } else {
+        xx = x * x; xy = x * y; xz = x * z; yy = y * y; yz = y * z; zz = z * z;
+      }
+    }
+    pp[0] = xx; pp[1] = xy; pp[2] = xz; pp[3] = yy; pp[4] = yz; pp[5] = zz;
+  }
+
+  const bool valid = prm.valid_thr >= 0 && static_cast<long long>(valid_pts) >= prm.valid_thr && cont;
+
+  PlaneFit fit;
+  fit_plane(sum, pp, n, fit);
+
+  // hasSmallPlaneError (cell_segment.cpp:99-102)
+  const float mz = fit.mean[2];
+  const float thr = prm.sigma_coeff * (mz * mz) + prm.sigma_margin;
+  const bool planar = valid && (static_cast<double>(fit.mse) <= static_cast<double>(thr) * static_cast<double>(thr));
+  // calculateMergeTolerance (cell_segment.cpp:104-110), min_merge_dist 20
+  const float dx = fx0 - lx, dy = fy0 - ly, dz = fz0 - lz;
+  const float diam = __builtin_sqrtf(dx * dx + (dy * dy + dz * dz));
+  float t = diam * prm.tol_sin;
+  t = (t < 20.0f) ? 20.0f : t;                      // std::max(t, 20)
+  t = (prm.max_merge_dist < t) ? prm.max_merge_dist : t;  // std::min(t, max)
+  const float tol = t * t;
+
+  // histogram bin (normals_histogram.cpp:32-45), planar cells only (plane_extractor.cpp:286-291)
+  uint32_t bin1 = 0;
+  if (planar) {
+    const float nx = fit.normal[0], ny = fit.normal[1], nz = fit.normal[2];
+    const bool is_zero = __builtin_fabsf(nx) <= 1e-5f && __builtin_fabsf(ny) <= 1e-5f && __builtin_fabsf(nz) <= 1e-5f;
+    if (!is_zero) {
+      const double dnx = nx, dny = ny;
+      const double proj = dpxm::dsqrt(dnx * dnx + dny * dny);
+      const double polar = dpxm::dacos(static_cast<double>(-nz));
+      const double azim = dpxm::datan2(dnx / proj, dny / proj);
+      const double kPi = 3.14159265358979323846;
+      const int B = prm.hist_B;
+      const int Xq = static_cast<int>((B - 1) * (polar - 0.0) / (kPi - 0.0));
+      int Yq = 0;
+      // azim is NaN only when nx == ny == 0; the reference then has Xq == 0 (normal (0,0,-1)) and never
+      // evaluates Yq, or reads out of bounds for a (0,0,+1) normal (undefined there; defined as 0 here).
+      if (Xq > 0 && azim == azim) Yq = static_cast<int>((B - 1) * (azim - (-kPi)) / (kPi - (-kPi)));
+      bin1 = static_cast<uint32_t>(Yq * B + Xq) + 1u;
+    }
+  }
+
+  if (valid) {
+    out.sum[0] = sum[0]; out.sum[1] = sum[1]; out.sum[2] = sum[2];
+    out.pp[0] = pp[0]; out.pp[1] = pp[1]; out.pp[2] = pp[2]; out.pp[3] = pp[3]; out.pp[4] = pp[4]; out.pp[5] = pp[5];
+    out.normal[0] = fit.normal[0]; out.normal[1] = fit.normal[1]; out.normal[2] = fit.normal[2];
+    out.d = fit.d;
+    out.mse = fit.mse;
+    out.tol = tol;
+    out.info = CELL_VALID | (planar ? CELL_PLANAR : 0u) | (fit.path != 0 ? CELL_QL : 0u) | (bin1 << 8);
+  } else {
+    // reference leaves the default-constructed stat (mse = FLT_MAX, score 0) — cell_segment_stat.cpp:27
+    out.sum[0] = out.sum[1] = out.sum[2] = 0.f;
+    out.pp[0] = out.pp[1] = out.pp[2] = out.pp[3] = out.pp[4] = out.pp[5] = 0.f;
+    out.normal[0] = out.normal[1] = out.normal[2] = 0.f;
+    out.d = 0.f;
+    out.mse = 3.402823466e+38f;
+    out.tol = 0.f;
+    out.info = 0u;
+  }
+}
+
+// v1 launch shape: one thread per cell, 256-thread blocks over batch*C cells.
+template <int PT, bool DEPTH>
+__global__ __launch_bounds__(256) void k_planefit(Params prm, const void* __restrict__ in, dpx_cell* __restrict__ cells) {
+  const long long gid = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  const long long total = static_cast<long long>(prm.batch) * prm.C;
+  if (gid >= total) return;
+  const int frame = static_cast<int>(gid / prm.C);
+  const int c = static_cast<int>(gid - static_cast<long long>(frame) * prm.C);
+  const int cr = c / prm.nh, cc = c - cr * prm.nh;
+  PointSrc<DEPTH> src;
+  src.base = DEPTH ? static_cast<const void*>(static_cast<const uint16_t*>(in) + static_cast<long long>(frame) * prm.N)
+                   : static_cast<const void*>(static_cast<const float*>(in) + 3ll * frame * prm.N);
+  src.W = prm.W;
+  src.fx = prm.fx; src.fy = prm.fy; src.cx = prm.cx; src.cy = prm.cy;
+  src.sheared = prm.sheared;
+  dpx_cell rec;
+  planefit_cell<PT, DEPTH>(prm, src, cr, cc, rec);
+  // 64-byte record as four 16-byte stores
+  float4* dst = reinterpret_cast<float4*>(cells + gid);
+  const float4* s4 = reinterpret_cast<const float4*>(&rec);
+  dst[0] = s4[0];
+  dst[1] = s4[1];
+  dst[2] = s4[2];
+  dst[3] = s4[3];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K3: directed edge bits.  Edge u->v is set iff both cells are planar and growSeed would accept v from u
+// ignoring the dynamic unassigned/activated state (plane_extractor.cpp:377-383):
+//   n_u . n_v >= min_cos  &&  (n_u . mean_v + d_u)^2 <= tol_v        (comparisons in double)
+// Output: one uint32 per cell: bits 0..7 flags (F_UNASSIGNED, F_EDGE0<<dir), bits 8..31 histogram bin + 1.
+__global__ __launch_bounds__(256) void k_cellgraph(Params prm, const dpx_cell* __restrict__ cells, uint32_t* __restrict__ meta) {
+  const long long gid = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  const long long total = static_cast<long long>(prm.batch) * prm.C;
+  if (gid >= total) return;
+  const int frame = static_cast<int>(gid / prm.C);
+  const int c = static_cast<int>(gid - static_cast<long long>(frame) * prm.C);
+  const int cr = c / prm.nh, cc = c - cr * prm.nh;
+  const dpx_cell* fc = cells + static_cast<long long>(frame) * prm.C;
+  const uint32_t info = fc[c].info;
+  uint32_t m = 0;
+  if (info & CELL_PLANAR) {
+    m = F_UNASSIGNED | (info & 0xFFFFFF00u);
+    const float nx = fc[c].normal[0], ny = fc[c].normal[1], nz = fc[c].normal[2];
+    const double du = static_cast<double>(fc[c].d);
+    const float nf = static_cast<float>(prm.n);
+    const int nb[4] = {cr >= 1 ? c - prm.nh : -1, cr + 1 < prm.nv ? c + prm.nh : -1, cc >= 1 ? c - 1 : -1,
+                       cc + 1 < prm.nh ? c + 1 : -1};
+#pragma unroll
+    for (int dir = 0; dir < 4; ++dir) {
+      const int v = nb[dir];
+      if (v < 0) continue;
+      const dpx_cell& cv = fc[v];
+      if (!(cv.info & CELL_PLANAR)) continue;
+      const float cosf_ = dot3(nx, ny, nz, cv.normal[0], cv.normal[1], cv.normal[2]);
+      const float mx = cv.sum[0] / nf, my = cv.sum[1] / nf, mzv = cv.sum[2] / nf;  // mean_ = coord_sum_/nr_pts_
+      const double tt = static_cast<double>(dot3(nx, ny, nz, mx, my, mzv)) + du;
+      const double dist = tt * tt;
+      if (static_cast<double>(cosf_) >= static_cast<double>(prm.min_cos) && dist <= static_cast<double>(cv.tol))
+        m |= (F_EDGE0 << dir);
+    }
+  }
+  meta[gid] = m;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K6: toImageLabels (plane_extractor.cpp:455-470).  cell_labels already hold merge[L-1]+1 (or 0).
+// One thread writes 4 consecutive pixels (16-byte store).  Pixels outside the nv*P x nh*P grid (image size
+// not a multiple of P: out-of-bounds read in the reference) are defined as 0.
+__global__ __launch_bounds__(256) void k_labels(Params prm, const int32_t* __restrict__ cell_labels, int32_t* __restrict__ labels) {
+  const int W4 = (prm.W + 3) >> 2;
+  const long long per_frame = static_cast<long long>(prm.H) * W4;
+  const long long gid = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (gid >= per_frame * prm.batch) return;
+  const int frame = static_cast<int>(gid / per_frame);
+  const long long r = gid - frame * per_frame;
+  const int row = static_cast<int>(r / W4);
+  const int col = static_cast<int>(r - static_cast<long long>(row) * W4) * 4;
+  const int cr = row / prm.P;
+  const int32_t* cl = cell_labels + static_cast<long long>(frame) * prm.C + static_cast<long long>(cr) * prm.nh;
+  int32_t v[4];
+  int cc = col / prm.P;
+  int rem = col - cc * prm.P;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[i] = (cr < prm.nv && cc < prm.nh) ? cl[cc] : 0;
+    if (++rem == prm.P) {
+      rem = 0;
+      ++cc;
+    }
+  }
+  int32_t* dst = labels + static_cast<long long>(frame) * prm.N + static_cast<long long>(row) * prm.W + col;
+  if (col + 3 < prm.W && ((prm.W & 3) == 0)) {
+    *reinterpret_cast<int4*>(dst) = make_int4(v[0], v[1], v[2], v[3]);
+  } else {
+    for (int i = 0; i < 4; ++i)
+      if (col + i < prm.W) dst[i] = v[i];
+  }
+}
+
+// DepthImage::toPointCloud (utils/depth_image.cpp:55-78) as a stand-alone kernel for the utils API.
+__global__ __launch_bounds__(256) void k_backproject(const uint16_t* __restrict__ depth, int H, int W, float fx, float fy,
+                                                     float cx, float cy, float* __restrict__ xyz) {
+  const long long gid = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (gid >= static_cast<long long>(H) * W) return;
+  const int row = static_cast<int>(gid / W), col = static_cast<int>(gid - static_cast<long long>(row) * W);
+  const float z = static_cast<float>(depth[gid]);
+  xyz[3 * gid + 0] = ((static_cast<float>(col) - cx) * z) / fx;
+  xyz[3 * gid + 1] = ((static_cast<float>(row) - cy) * z) / fy;
+  xyz[3 * gid + 2] = z;
+}
+
+}  // namespace dpx

@@ -1,0 +1,180 @@
+"""Python mirror of the reference's `deplex.plane_extraction` module over the C-ABI.
+
+Reference surface (cpp/pybind/plane_extraction/plane_extraction.cpp:28-37):
+    Config(path: str)
+    PlaneExtractor(image_height, image_width, config=Config()).process(pcd_array) -> 1-D int32 labels
+Added (not in the reference): batched depth entry points and the per-plane / per-cell records the
+acceptance criteria grade.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _capi
+from ._capi import DeplexError, DpxConfig
+
+_FIELDS = [f[0] for f in DpxConfig._fields_]
+
+
+class Config:
+    """deplex::config::Config — defaults of cpp/deplex/include/deplex/config.h:51-81; `Config(path)` parses
+    an .ini exactly like cpp/deplex/src/deplex/config.cpp:28-80 (the parser lives in the C-ABI library)."""
+
+    def __init__(self, path: Optional[str] = None, **overrides):
+        self._c = DpxConfig()
+        if path is None:
+            _capi.lib().dpx_default_config(C.byref(self._c))
+        else:
+            _capi.check(_capi.lib().dpx_config_from_ini(str(path).encode(), C.byref(self._c)))
+        for k, v in overrides.items():
+            setattr(self, k, v)
+
+    def __getattr__(self, name):
+        if name in _FIELDS:
+            v = getattr(self.__dict__["_c"], name)
+            return bool(v) if name == "ransac_refinement" else v
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        if name == "_c":
+            object.__setattr__(self, name, value)
+        elif name in _FIELDS:
+            setattr(self._c, name, int(value) if isinstance(value, (bool, np.bool_)) else value)
+        else:
+            raise AttributeError(f"Config has no parameter {name!r}")
+
+    def copy(self) -> "Config":
+        c = Config()
+        C.memmove(C.byref(c._c), C.byref(self._c), C.sizeof(DpxConfig))
+        return c
+
+    def __repr__(self):
+        return "Config(" + ", ".join(f"{k}={getattr(self, k)!r}" for k in _FIELDS) + ")"
+
+
+class PlaneExtractor:
+    """deplex::PlaneExtractor (cpp/deplex/include/deplex/plane_extractor.h:28-56).
+
+    Construction errors and process() shape errors raise DeplexError (a RuntimeError) carrying the
+    reference's messages (plane_extractor.cpp:161-164, :188-194).
+    """
+
+    def __init__(self, image_height: int, image_width: int, config: Optional[Config] = None, *, max_batch: int = 1,
+                 device: int = 0):
+        self._h = C.c_void_p()
+        cfg = config if config is not None else Config()
+        self.image_height, self.image_width = int(image_height), int(image_width)
+        self.max_batch = int(max_batch)
+        self.device = int(device)
+        _capi.check(_capi.lib().dpx_create(C.byref(cfg._c), self.image_height, self.image_width, self.max_batch,
+                                          self.device, C.byref(self._h)))
+        nh, nv = C.c_int32(), C.c_int32()
+        _capi.check(_capi.lib().dpx_grid_dims(self._h, C.byref(nh), C.byref(nv)))
+        self.nh, self.nv = nh.value, nv.value
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                _capi.lib().dpx_destroy(h)
+            except Exception:
+                pass
+            self._h = C.c_void_p()
+
+    close = __del__
+
+    # ---- reference API -------------------------------------------------------------------------------
+    def process(self, pcd_array) -> np.ndarray:
+        """Labels for one organised cloud.  Accepts any (N, 3) float array (float64 is cast to float32 with
+        round-to-nearest, like pybind11's Eigen caster does for the reference)."""
+        pcd = np.ascontiguousarray(np.asarray(pcd_array), dtype=np.float32)
+        if pcd.ndim != 2 or pcd.shape[1] != 3:
+            raise TypeError("process(): pcd_array must have shape (N, 3)")  # pybind's Eigen caster rejects it too
+        n = pcd.shape[0]
+        labels = np.zeros(max(n, 1), dtype=np.int32)
+        _capi.check(_capi.lib().dpx_process_pcd(self._h, pcd.ctypes.data if pcd.size else None, n,
+                                               labels.ctypes.data))
+        return labels[:n]
+
+    # ---- batched / fused entry points ----------------------------------------------------------------
+    def process_depth_batch(self, depth, fx, fy, cx, cy) -> np.ndarray:
+        """depth: (B, H, W) uint16 -> labels (B, H*W) int32; back-projection fused on the device."""
+        depth = np.ascontiguousarray(depth, dtype=np.uint16)
+        if depth.ndim == 2:
+            depth = depth[None]
+        b, h, w = depth.shape
+        if (h, w) != (self.image_height, self.image_width):
+            raise DeplexError(_capi.DPX_ERR_SHAPE, f"Error! Number of points doesn't match image shape: {h * w} != "
+                              f"{self.image_height} x {self.image_width}")
+        labels = np.empty((b, h * w), dtype=np.int32)
+        _capi.check(_capi.lib().dpx_process_depth_batch(self._h, depth.ctypes.data, b, fx, fy, cx, cy,
+                                                       labels.ctypes.data))
+        return labels
+
+    def process_pcd_batch(self, pcd) -> np.ndarray:
+        pcd = np.ascontiguousarray(pcd, dtype=np.float32)
+        b = pcd.shape[0]
+        if pcd.shape[1:] != (self.image_height * self.image_width, 3):
+            raise DeplexError(_capi.DPX_ERR_SHAPE, "Error! Number of points doesn't match image shape: "
+                              f"{pcd.shape[1]} != {self.image_height} x {self.image_width}")
+        labels = np.empty((b, pcd.shape[1]), dtype=np.int32)
+        _capi.check(_capi.lib().dpx_process_pcd_batch(self._h, pcd.ctypes.data, b, labels.ctypes.data))
+        return labels
+
+    def process_depth_device(self, d_depth_ptr: int, batch: int, fx, fy, cx, cy, d_labels_ptr: int, stream: int = 0):
+        """Stream-ordered, device pointers (e.g. torch tensors' data_ptr()); no synchronisation."""
+        _capi.check(_capi.lib().dpx_process_depth_batch_device(self._h, d_depth_ptr, batch, fx, fy, cx, cy,
+                                                              d_labels_ptr, stream))
+
+    def process_pcd_device(self, d_xyz_ptr: int, batch: int, d_labels_ptr: int, stream: int = 0):
+        _capi.check(_capi.lib().dpx_process_pcd_batch_device(self._h, d_xyz_ptr, batch, d_labels_ptr, stream))
+
+    # ---- records of the last call -----------------------------------------------------------------------
+    def cells(self, frame: int = 0) -> np.ndarray:
+        out = np.zeros(self.nh * self.nv, dtype=_capi.CELL_DTYPE)
+        _capi.check(_capi.lib().dpx_get_cells(self._h, frame, out.ctypes.data))
+        return out
+
+    def cell_edges(self, frame: int = 0) -> np.ndarray:
+        out = np.zeros(max(self.nh * self.nv, 1), dtype=np.uint8)
+        _capi.check(_capi.lib().dpx_get_cell_edges(self._h, frame, out.ctypes.data))
+        return out[: self.nh * self.nv]
+
+    def cell_labels(self, frame: int = 0) -> np.ndarray:
+        out = np.zeros(max(self.nh * self.nv, 1), dtype=np.int32)
+        _capi.check(_capi.lib().dpx_get_cell_labels(self._h, frame, out.ctypes.data))
+        return out[: self.nh * self.nv].reshape(self.nv, self.nh)
+
+    def planes(self, frame: int = 0) -> np.ndarray:
+        st = self.frame_stats(frame)
+        n = int(st["segments"])
+        out = np.zeros(max(n, 1), dtype=_capi.PLANE_DTYPE)
+        got = C.c_int32()
+        _capi.check(_capi.lib().dpx_get_planes(self._h, frame, out.ctypes.data, n, C.byref(got)))
+        return out[:n]
+
+    def frame_stats(self, frame: int = 0):
+        out = np.zeros(1, dtype=_capi.STATS_DTYPE)
+        _capi.check(_capi.lib().dpx_get_frame_stats(self._h, frame, out.ctypes.data))
+        return out[0]
+
+    # ---- measurement ------------------------------------------------------------------------------------
+    def set_profiling(self, enable: bool) -> None:
+        _capi.check(_capi.lib().dpx_set_profiling(self._h, int(enable)))
+
+    def kernel_ms(self) -> dict:
+        ms = (C.c_float * 4)()
+        _capi.check(_capi.lib().dpx_get_kernel_ms(self._h, ms))
+        return dict(zip(_capi.K_NAMES, list(ms)))
+
+    def time_planefit(self, d_in_ptr: int, input_kind: int, batch: int, fx, fy, cx, cy, iters: int, stream: int = 0) -> float:
+        ms = C.c_float()
+        _capi.check(_capi.lib().dpx_time_planefit(self._h, d_in_ptr, input_kind, batch, fx, fy, cx, cy, iters, stream,
+                                                 C.byref(ms)))
+        return ms.value
+
+    def planefit_bytes(self, input_kind: int, batch: int) -> int:
+        return int(_capi.lib().dpx_planefit_bytes(self._h, input_kind, batch))

@@ -1,0 +1,169 @@
+/* deplex_amd.h — C-ABI of the MI355X-native depth-plane extractor.
+ *
+ * Drop-in boundary for prime-slam/deplex's hot path PlaneExtractor::process().  Every entry point
+ * names the reference interface it replaces (paths relative to the reference checkout).  Plain
+ * pointers and sizes only; no C++/torch types.  The library is libdeplex_amd.so, built by
+ * __graft_entry__.build() with hipcc --offload-arch=gfx950.  All compute runs in hand-written HIP
+ * kernels; there is no CPU fallback — calls fail with DPX_ERR_HIP / DPX_ERR_NO_DEVICE without a GPU.
+ *
+ * Threading: a handle is not re-entrant (like a reference PlaneExtractor instance, whose labels_map_
+ * is mutable scratch, plane_extractor.cpp:76); distinct handles are independent.
+ */
+#ifndef DEPLEX_AMD_H
+#define DEPLEX_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* POD mirror of deplex::config::Config, same field order and defaults
+ * (cpp/deplex/include/deplex/config.h:51-81). */
+typedef struct dpx_config {
+  int32_t patch_size;                         /* patchSize                      10 */
+  int32_t histogram_bins_per_coord;           /* histogramBinsPerCoord          20 */
+  float min_cos_angle_merge;                  /* minCosAngleForMerge          0.90 */
+  float max_merge_dist;                       /* maxMergeDist                  500 */
+  int32_t min_region_growing_candidate_size;  /* minRegionGrowingCandidateSize   5 */
+  int32_t min_region_growing_cells_activated; /* minRegionGrowingCellsActivated  4 */
+  float min_region_planarity_score;           /* minRegionPlanarityScore      0.55 */
+  float depth_sigma_coeff;                    /* depthSigmaCoeff          1.425e-6 */
+  float depth_sigma_margin;                   /* depthSigmaMargin               10 */
+  int32_t min_pts_per_cell;                   /* minPtsPerCell                   3 */
+  float depth_discontinuity_threshold;        /* depthDiscontinuityThreshold   160 */
+  int32_t max_number_depth_discontinuity;     /* maxNumberDepthDiscontinuity     1 */
+  int32_t ransac_refinement;                  /* ransacRefinement                0 */
+  int32_t ransac_max_iterations;              /* ransacMaxIterations          1000 */
+  float ransac_threshold;                     /* ransacThreshold                 1 */
+  float ransac_inliers_ratio;                 /* ransacInliersRatio            0.9 */
+} dpx_config;
+
+/* Per-cell record the plane-fit kernel writes (64 bytes, one per grid cell, cell = row*nh + col).
+ * Fields follow CellSegmentStat / CellSegment (cell_segment_stat.h:62-69, cell_segment.h). */
+typedef struct dpx_cell {
+  float sum[3];    /* coord_sum_ */
+  float pp[6];     /* variance_: xx xy xz yy yz zz */
+  float normal[3]; /* normal_ */
+  float d;         /* d_ */
+  float mse;       /* mse_ (FLT_MAX when the cell is not valid) */
+  float tol;       /* merge_tolerance_ */
+  uint32_t info;   /* bit0 valid, bit1 planar, bit2 eigensolver used QL, bits 8..31 histogram bin + 1 (0 = none) */
+} dpx_cell;
+
+/* Per-plane record (one per grown segment, in creation order; state after findMergedLabels,
+ * plane_extractor.cpp:394-426).  The reference keeps these private; exported here because the
+ * acceptance criteria grade fitted plane parameters. */
+typedef struct dpx_plane {
+  float sum[3];
+  float pp[6];
+  float mean[3];
+  float normal[3];
+  float d, mse, score;
+  int32_t n_pts;       /* nr_pts_ */
+  int32_t n_cells;     /* cells activated by the grow that created the segment */
+  int32_t merge_label; /* plane_merge_labels[i], 0-based; label in the image = merge_label + 1 */
+} dpx_plane;
+
+typedef struct dpx_frame_stats {
+  int32_t planar_cells;
+  int32_t grows;
+  int32_t activations;
+  int32_t segments;
+  int32_t merges;
+  int32_t overflow; /* non-zero if an internal capacity was exceeded (results for the frame invalid) */
+} dpx_frame_stats;
+
+typedef struct dpx_handle_s* dpx_handle;
+
+enum {
+  DPX_OK = 0,
+  DPX_ERR_PATCH_ZERO = -1, /* reference throws at construction, plane_extractor.cpp:161-164 */
+  DPX_ERR_SHAPE = -2,      /* reference throws in process(), plane_extractor.cpp:188-194 */
+  DPX_ERR_UNDEFINED = -3,  /* configuration the reference leaves undefined (negative patchSize, minPtsPerCell==0, ...) */
+  DPX_ERR_HIP = -4,
+  DPX_ERR_ARG = -5,
+  DPX_ERR_CAPACITY = -6,
+  DPX_ERR_NO_DEVICE = -7,
+  DPX_ERR_IO = -8
+};
+
+/* Kernel indices for dpx_get_kernel_ms(). */
+enum { DPX_K_PLANEFIT = 0, DPX_K_CELLGRAPH = 1, DPX_K_REGIONS = 2, DPX_K_LABELS = 3, DPX_K_COUNT = 4 };
+
+/* Config::Config() defaults — config.h:51-81. */
+void dpx_default_config(dpx_config* cfg);
+
+/* Config::Config(std::string const& config_path) — config.cpp:28-80 (same key names, no trimming, '#' comments,
+ * std::stoi/std::stof prefix parsing).  DPX_ERR_IO with message "Couldn't open ini file: <path>" if unreadable,
+ * DPX_ERR_ARG if a value does not parse (the reference lets std::invalid_argument escape). */
+int dpx_config_from_ini(const char* path, dpx_config* cfg);
+
+/* PlaneExtractor::PlaneExtractor(int32_t image_height, int32_t image_width, config::Config) —
+ * plane_extractor.h:39, plane_extractor.cpp:153-176,182-183.  Also allocates device scratch for up to
+ * max_batch frames per call on HIP device `device`. */
+int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width, int32_t max_batch, int32_t device,
+               dpx_handle* out);
+
+/* PlaneExtractor::~PlaneExtractor — plane_extractor.cpp:178. */
+void dpx_destroy(dpx_handle h);
+
+/* Message of the last failing call on this thread (the reference's exception text for its throwing cases). */
+const char* dpx_last_error(void);
+
+/* Eigen::VectorXi PlaneExtractor::process(Eigen::MatrixX3f const& pcd_array) — plane_extractor.h:48,
+ * plane_extractor.cpp:185-283.  xyz: n_points x 3 row-major float32 organised cloud in HOST memory
+ * (row index = image_row*W + image_col); labels: n_points int32 in HOST memory, 0 = non-planar.
+ * Returns DPX_ERR_SHAPE (with the reference's message) when n_points != H*W. */
+int dpx_process_pcd(dpx_handle h, const float* xyz, int64_t n_points, int32_t* labels);
+
+/* Batched form of the same call: `batch` clouds back to back. */
+int dpx_process_pcd_batch(dpx_handle h, const float* xyz, int32_t batch, int32_t* labels);
+
+/* DepthImage::toPointCloud(K) followed by PlaneExtractor::process() for `batch` depth frames, fused on the
+ * device (utils/depth_image.cpp:55-78 + plane_extractor.cpp:185-283).  depth: batch x H x W uint16 (HOST),
+ * labels: batch x H x W int32 (HOST). */
+int dpx_process_depth_batch(dpx_handle h, const uint16_t* depth, int32_t batch, float fx, float fy, float cx,
+                            float cy, int32_t* labels);
+
+/* Device-pointer, stream-ordered forms (no copies, no synchronisation): d_* are device pointers on the
+ * handle's device, hip_stream is a hipStream_t (NULL = default stream).  Used by pipelines and bench.py. */
+int dpx_process_depth_batch_device(dpx_handle h, const void* d_depth, int32_t batch, float fx, float fy, float cx,
+                                   float cy, void* d_labels, void* hip_stream);
+int dpx_process_pcd_batch_device(dpx_handle h, const void* d_xyz, int32_t batch, void* d_labels, void* hip_stream);
+
+/* DepthImage::toPointCloud — utils/depth_image.cpp:55-78: depth H x W uint16 (HOST) -> xyz N x 3 float32 (HOST). */
+int dpx_backproject(const uint16_t* depth, int32_t height, int32_t width, float fx, float fy, float cx, float cy,
+                    float* xyz, int32_t device);
+
+/* Results of the last process call on this handle (synchronises the handle's last stream). */
+int dpx_grid_dims(dpx_handle h, int32_t* nh, int32_t* nv);
+int dpx_get_cells(dpx_handle h, int32_t frame, dpx_cell* out);               /* nh*nv records */
+int dpx_get_cell_edges(dpx_handle h, int32_t frame, uint8_t* out);           /* nh*nv bytes: bit0 planar, bits2..5 edge U,D,L,R */
+int dpx_get_cell_labels(dpx_handle h, int32_t frame, int32_t* out);          /* nh*nv merged labels (toImageLabels input) */
+int dpx_get_planes(dpx_handle h, int32_t frame, dpx_plane* out, int32_t cap, int32_t* n_out);
+int dpx_get_frame_stats(dpx_handle h, int32_t frame, dpx_frame_stats* out);
+
+/* Measurement hooks. */
+/* When enabled, every process call brackets each kernel with HIP events on the launch stream. */
+int dpx_set_profiling(dpx_handle h, int32_t enable);
+/* Milliseconds per kernel (DPX_K_*) of the last profiled call; synchronises. */
+int dpx_get_kernel_ms(dpx_handle h, float* ms /* DPX_K_COUNT */);
+/* Launch only the plane-fit kernel `iters` times on `hip_stream` over a device-resident batch and return the
+ * average duration in ms measured with HIP events on that stream (input_kind: 0 depth uint16, 1 xyz float32). */
+int dpx_time_planefit(dpx_handle h, const void* d_in, int32_t input_kind, int32_t batch, float fx, float fy,
+                      float cx, float cy, int32_t iters, void* hip_stream, float* avg_ms);
+/* Algorithmic bytes one plane-fit launch moves for `batch` frames (input + cell records). */
+int64_t dpx_planefit_bytes(dpx_handle h, int32_t input_kind, int32_t batch);
+
+/* Exercises dpx_math.h and the 3x3 eigensolver on the device (parity tests): n inputs each.
+ * which: 0 atan2(a,b) 1 sin(a) 2 cos(a) 3 acos(a) 4 sqrt(a).  Host pointers. */
+int dpx_test_math(int32_t which, const double* a, const double* b, double* out, int64_t n, int32_t device);
+/* A: n x 6 (a00 a01 a02 a11 a12 a22); Q: n x 9 row-major; w: n x 3; rc: n (0 analytic, 1 QL, -1 no convergence). */
+int dpx_test_eig3(const double* A, double* Q, double* w, int32_t* rc, int64_t n, int32_t device);
+
+const char* dpx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEPLEX_AMD_H */
