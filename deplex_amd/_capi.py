@@ -96,6 +96,26 @@ class DeplexError(RuntimeError):
         self.code = code
 
 
+def _preload_hip_runtime() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP runtimes in one
+    process cannot both own the GPU, so bind to the copy torch will use: load it by path first (without importing
+    torch); libdeplex_amd.so's NEEDED libamdhip64.so.7 then resolves to it, and a later `import torch` finds the
+    same file already mapped."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = Path(spec.origin).parent / "lib" / "libamdhip64.so"
+    if cand.exists():
+        try:
+            C.CDLL(str(cand), mode=getattr(os, "RTLD_GLOBAL", 256) | getattr(os, "RTLD_NOW", 2))
+        except OSError:
+            pass
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -103,6 +123,7 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). deplex_amd has no CPU fallback.")
+        _preload_hip_runtime()
         L = C.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol

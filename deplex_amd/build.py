@@ -1,0 +1,45 @@
+"""Builds libdeplex_amd.so (HIP kernels + C-ABI) in-tree with hipcc for gfx950."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+SRC = PKG / "csrc"
+OUT = PKG / "lib" / "libdeplex_amd.so"
+# -ffp-contract=off: the reference is built without FMA and every f32/f64 product must round
+# before the following add for results to be bit-identical.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+         "-Wno-unused-value", "-Wno-pass-failed"]
+
+
+def sources():
+    return [SRC / "dpx_api.hip", SRC / "dpx_kernels.h", SRC / "dpx_regions.h", SRC / "dpx_fit.h", SRC / "dpx_math.h",
+            PKG.parent / "include" / "deplex_amd.h"]
+
+
+def needs_build() -> bool:
+    if not OUT.exists():
+        return True
+    t = OUT.stat().st_mtime
+    return any(s.stat().st_mtime > t for s in sources())
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    if not force and not needs_build():
+        return OUT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    OUT.parent.mkdir(parents=True, exist_ok=True)
+    tmp = OUT.with_suffix(".so.tmp")
+    cmd = [hipcc, *FLAGS, str(SRC / "dpx_api.hip"), "-o", str(tmp)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    os.replace(tmp, OUT)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

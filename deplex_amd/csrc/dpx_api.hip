@@ -64,10 +64,12 @@ struct dpx_handle_s {
   size_t d_in_bytes = 0;
   int32_t* d_labels = nullptr;
   size_t d_labels_bytes = 0;
-  // profiling
+  // profiling: a ring of event sets, one per process call
   bool profiling = false;
-  hipEvent_t ev[DPX_K_COUNT + 1] = {};
-  bool ev_valid = false;
+  static constexpr int kProfSlots = 128;
+  hipEvent_t ev[kProfSlots][DPX_K_COUNT + 1] = {};
+  bool ev_created = false;
+  long long prof_calls = 0;
   int last_batch = 0;
 };
 
@@ -97,8 +99,9 @@ void free_all(dpx_handle h) {
   hipFree(h->d_gqueue);
   hipFree(h->d_in);
   hipFree(h->d_labels);
-  for (auto& e : h->ev)
-    if (e) hipEventDestroy(e);
+  for (auto& slot : h->ev)
+    for (auto& e : slot)
+      if (e) hipEventDestroy(e);
   if (h->stream) hipStreamDestroy(h->stream);
 }
 
@@ -128,18 +131,19 @@ int run_pipeline(dpx_handle h, const void* d_in, bool depth, int batch, float fx
   prm.batch = batch;
   prm.fx = fx; prm.fy = fy; prm.cx = cx; prm.cy = cy;
   const bool prof = h->profiling;
-  if (prof) DPX_HIP(hipEventRecord(h->ev[0], s));
+  hipEvent_t* ev = h->ev[h->prof_calls % dpx_handle_s::kProfSlots];
+  if (prof) DPX_HIP(hipEventRecord(ev[0], s));
   if (prm.C > 0) {
     if (depth)
       launch_planefit<true>(prm, d_in, h->d_cells, s);
     else
       launch_planefit<false>(prm, d_in, h->d_cells, s);
   }
-  if (prof) DPX_HIP(hipEventRecord(h->ev[1], s));
+  if (prof) DPX_HIP(hipEventRecord(ev[1], s));
   const long long total = static_cast<long long>(batch) * prm.C;
   if (total > 0)
     hipLaunchKernelGGL(dpx::k_cellgraph, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, prm, h->d_cells, h->d_meta);
-  if (prof) DPX_HIP(hipEventRecord(h->ev[2], s));
+  if (prof) DPX_HIP(hipEventRecord(ev[2], s));
   dpx::RegionBufs rb{};
   rb.cells = h->d_cells; rb.meta = h->d_meta; rb.order = h->d_order; rb.grow_start = h->d_grow_start;
   rb.cand = h->d_cand; rb.planes = h->d_planes; rb.cell_labels = h->d_cell_labels; rb.pairs = h->d_pairs;
@@ -149,7 +153,7 @@ int run_pipeline(dpx_handle h, const void* d_in, bool depth, int batch, float fx
     hipLaunchKernelGGL(dpx::k_regions<true>, dim3(batch), dim3(64), h->lds_bytes, s, prm, rb);
   else
     hipLaunchKernelGGL(dpx::k_regions<false>, dim3(batch), dim3(64), h->lds_bytes, s, prm, rb);
-  if (prof) DPX_HIP(hipEventRecord(h->ev[3], s));
+  if (prof) DPX_HIP(hipEventRecord(ev[3], s));
   {
     const long long per_frame = static_cast<long long>(prm.H) * ((prm.W + 3) / 4);
     const long long tot = per_frame * batch;
@@ -157,8 +161,8 @@ int run_pipeline(dpx_handle h, const void* d_in, bool depth, int batch, float fx
       hipLaunchKernelGGL(dpx::k_labels, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s, prm, h->d_cell_labels, d_labels);
   }
   if (prof) {
-    DPX_HIP(hipEventRecord(h->ev[4], s));
-    h->ev_valid = true;
+    DPX_HIP(hipEventRecord(ev[4], s));
+    ++h->prof_calls;
   }
   DPX_HIP(hipGetLastError());
   return DPX_OK;
@@ -389,8 +393,6 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
   }
   if (rc == DPX_OK && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
     rc = fail(DPX_ERR_HIP, "hipStreamCreate failed");
-  for (auto& ev : h->ev)
-    if (rc == DPX_OK && hipEventCreate(&ev) != hipSuccess) rc = fail(DPX_ERR_HIP, "hipEventCreate failed");
   if (rc == DPX_OK && h->lds_bytes > 48 * 1024) {
     hipError_t e2 = h->use_lds ? hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions<true>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds_bytes))
@@ -535,17 +537,32 @@ int dpx_get_planes(dpx_handle h, int32_t frame, dpx_plane* out, int32_t cap, int
 
 int dpx_set_profiling(dpx_handle h, int32_t enable) {
   if (!h) return fail(DPX_ERR_ARG, "null handle");
+  DPX_HIP(hipSetDevice(h->device));
+  if (enable && !h->ev_created) {
+    for (auto& slot : h->ev)
+      for (auto& e : slot) DPX_HIP(hipEventCreate(&e));
+    h->ev_created = true;
+  }
   h->profiling = enable != 0;
-  h->ev_valid = false;
+  h->prof_calls = 0;
   return DPX_OK;
 }
 
 int dpx_get_kernel_ms(dpx_handle h, float* ms) {
   if (!h || !ms) return fail(DPX_ERR_ARG, "null argument");
-  if (!h->ev_valid) return fail(DPX_ERR_ARG, "no profiled call recorded");
+  if (h->prof_calls == 0) return fail(DPX_ERR_ARG, "no profiled call recorded");
   DPX_HIP(hipSetDevice(h->device));
-  DPX_HIP(hipEventSynchronize(h->ev[DPX_K_COUNT]));
-  for (int k = 0; k < DPX_K_COUNT; ++k) DPX_HIP(hipEventElapsedTime(&ms[k], h->ev[k], h->ev[k + 1]));
+  const int n = static_cast<int>(std::min<long long>(h->prof_calls, dpx_handle_s::kProfSlots));
+  double acc[DPX_K_COUNT] = {};
+  for (int i = 0; i < n; ++i) {
+    DPX_HIP(hipEventSynchronize(h->ev[i][DPX_K_COUNT]));
+    for (int k = 0; k < DPX_K_COUNT; ++k) {
+      float t = 0.f;
+      DPX_HIP(hipEventElapsedTime(&t, h->ev[i][k], h->ev[i][k + 1]));
+      acc[k] += t;
+    }
+  }
+  for (int k = 0; k < DPX_K_COUNT; ++k) ms[k] = static_cast<float>(acc[k] / n);
   return DPX_OK;
 }
 

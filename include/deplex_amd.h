@@ -144,9 +144,10 @@ int dpx_get_planes(dpx_handle h, int32_t frame, dpx_plane* out, int32_t cap, int
 int dpx_get_frame_stats(dpx_handle h, int32_t frame, dpx_frame_stats* out);
 
 /* Measurement hooks. */
-/* When enabled, every process call brackets each kernel with HIP events on the launch stream. */
+/* When enabled, every process call brackets each kernel with HIP events on the launch stream (a ring of the
+ * last 128 calls is kept; enabling resets it). */
 int dpx_set_profiling(dpx_handle h, int32_t enable);
-/* Milliseconds per kernel (DPX_K_*) of the last profiled call; synchronises. */
+/* Average milliseconds per kernel (DPX_K_*) over the profiled calls recorded since enabling; synchronises. */
 int dpx_get_kernel_ms(dpx_handle h, float* ms /* DPX_K_COUNT */);
 /* Launch only the plane-fit kernel `iters` times on `hip_stream` over a device-resident batch and return the
  * average duration in ms measured with HIP events on that stream (input_kind: 0 depth uint16, 1 xyz float32). */

@@ -1,0 +1,302 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle on a real MI355X.
+
+Bit-exact for label maps, per-cell records and plane records (the oracle runs its "devmath" flavour, i.e. the same
+dpx_math.h transcendental code the device runs; tests/test_oracle.py shows that flavour and glibc give identical
+label maps).  Plane parameters are additionally compared against the glibc flavour within 1e-5 (north_star).
+"""
+import hashlib
+import json
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = {r["name"]: r for r in json.loads((Path(__file__).parent / "golden" / "oracle_goldens.json").read_text())["rows"]}
+
+
+def sha(labels):
+    return hashlib.sha256(np.ascontiguousarray(labels).astype("<i4").tobytes()).hexdigest()
+
+
+def to_cfg(D, ocfg):
+    c = D.Config()
+    for f, _ in ocfg._fields_:
+        setattr(c, f, getattr(ocfg, f))
+    return c
+
+
+def assert_cells_equal(gc, oc):
+    info = gc["info"]
+    valid = oc["valid"].astype(bool)
+    assert np.array_equal((info & 1) != 0, valid)
+    assert np.array_equal(((info >> 1) & 1), oc["planar"])
+    planar = oc["planar"].astype(bool)
+    assert np.array_equal((info >> 8).astype(np.int64)[planar] - 1, oc["bin"][planar])
+    assert np.array_equal(((info >> 2) & 1)[valid], oc["used_ql"][valid])
+    for f in ("sum", "pp", "normal", "d", "mse", "tol"):
+        assert np.array_equal(gc[f][valid].view(np.uint32), oc[f][valid].view(np.uint32)), f
+    assert np.all(gc["mse"][~valid] == np.float32(3.402823466e+38))
+
+
+def assert_planes_equal(gp, op):
+    assert len(gp) == len(op)
+    for f in ("sum", "pp", "mean", "normal", "d", "mse", "score"):
+        assert np.array_equal(gp[f].view(np.uint32), op[f].view(np.uint32)), f
+    for f in ("n_pts", "n_cells", "merge_label"):
+        assert np.array_equal(gp[f], op[f]), f
+
+
+def full_compare(D, O, depth, intr, ocfg, batch_api=True, xyz_api=False):
+    """Runs a batch through the HIP path and every frame through the oracle; compares everything."""
+    O.set_math("devmath")
+    B, H, W = depth.shape
+    ex = D.PlaneExtractor(H, W, to_cfg(D, ocfg), max_batch=B)
+    if xyz_api:
+        clouds = np.stack([O.backproject(d, intr[0], intr[1], intr[2], intr[3]) for d in depth])
+        labels = ex.process_pcd_batch(clouds)
+    else:
+        labels = ex.process_depth_batch(depth, *intr)
+    for k in range(B):
+        xyz = O.backproject(depth[k], intr[0], intr[1], intr[2], intr[3])
+        ol, oc, op, ocl, ost = O.process(ocfg, H, W, xyz, debug=True)
+        assert np.array_equal(labels[k], ol), f"frame {k}: label map differs"
+        assert_cells_equal(ex.cells(k), oc)
+        assert_planes_equal(ex.planes(k), op)
+        st = ex.frame_stats(k)
+        assert (st["planar_cells"], st["grows"], st["activations"], st["segments"], st["merges"]) == \
+               (ost["planar_cells"], ost["grows"], ost["activations"], ost["segments"], ost["merges"])
+    return labels
+
+
+@pytest.fixture(scope="module")
+def D():
+    import deplex_amd
+    return deplex_amd
+
+
+def test_tum_known_answer_and_goldens(D, oracle, tum_depth):
+    """cpp/tests/test_plane_extractor.cpp:27-33 through the drop-in API: DepthImage -> process -> max == 34."""
+    img = D.utils.DepthImage(str(synth.TUM_PNG))
+    assert (img.height, img.width) == (480, 640)
+    pcd = img.transform_to_pcd(D.utils.read_intrinsics(str(synth.TUM_K)))
+    assert pcd[:, 2].max() == 46655 and pcd[:, 2].min() == 0  # cpp/tests/test_depth_image.cpp:42-48
+    K = synth.read_K(synth.TUM_K)
+    assert np.array_equal(pcd.view(np.uint32), oracle.backproject(tum_depth, K[0, 0], K[1, 1], K[0, 2], K[1, 2]).view(np.uint32))
+    ex = D.PlaneExtractor(img.height, img.width)
+    labels = ex.process(pcd)
+    assert labels.max() == 34 and labels.size == pcd.shape[0] and labels.dtype == np.int32
+    assert sha(labels) == GOLD["tum_f32_default"]["sha256"]
+
+
+def test_tum_python_test_path(D, tum_depth):
+    """python/tests/test_plane_extraction.py:44-52: float64 cloud -> 34 planes, label count == N."""
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
+    from make_goldens import f64_backproject
+    pts = f64_backproject(tum_depth, synth.TUM_K)  # float64 -> cast by process()
+    ex = D.PlaneExtractor(image_height=480, image_width=640)
+    labels = ex.process(pts.astype(np.float64))
+    assert max(labels) == 34 and labels.size == pts.shape[0]
+    assert sha(labels) == GOLD["tum_f64_default"]["sha256"]
+
+
+def test_fixtures_full_parity(D, oracle, tum_depth, icl_depth):
+    Kt, Ki = synth.read_K(synth.TUM_K), synth.read_K(synth.ICL_K)
+    it = tuple(float(v) for v in (Kt[0, 0], Kt[1, 1], Kt[0, 2], Kt[1, 2]))
+    ii = tuple(float(v) for v in (Ki[0, 0], Ki[1, 1], Ki[0, 2], Ki[1, 2]))
+    l = full_compare(D, oracle, tum_depth[None], it, oracle.default_config())
+    assert sha(l[0]) == GOLD["tum_f32_default"]["sha256"]
+    l = full_compare(D, oracle, icl_depth[None], ii, oracle.default_config())
+    assert sha(l[0]) == GOLD["icl_default"]["sha256"]
+    l = full_compare(D, oracle, icl_depth[None], ii, oracle.config_from_ini(synth.ICL_INI))  # P=4, QL fallbacks
+    assert sha(l[0]) == GOLD["icl_ini"]["sha256"] and l[0].max() == 45
+    full_compare(D, oracle, icl_depth[None], ii, oracle.config_from_ini(synth.ICL_INI), xyz_api=True)
+
+
+def test_reference_zero_and_throw_cases(D, tum_depth):
+    """cpp/tests/test_plane_extractor.cpp:35-88."""
+    K = D.utils.read_intrinsics(str(synth.TUM_K))
+    pts = D.utils.DepthImage(str(synth.TUM_PNG)).transform_to_pcd(K)
+    cfg = D.Config(str(synth.TUM_INI))
+    cfg.min_region_planarity_score = 5000
+    labels = D.PlaneExtractor(480, 640, cfg).process(pts)
+    assert not labels.any() and labels.size == pts.shape[0]
+    cfg = D.Config(str(synth.TUM_INI))
+    cfg.patch_size = int(1e6)
+    labels = D.PlaneExtractor(480, 640, cfg).process(pts)
+    assert not labels.any() and labels.size == pts.shape[0]
+    labels = D.PlaneExtractor(480, 640).process(np.zeros((640 * 480, 3), np.float32))
+    assert not labels.any() and labels.size == 640 * 480
+    cfg = D.Config(str(synth.TUM_INI))
+    cfg.patch_size = 0
+    with pytest.raises(RuntimeError) as e:
+        D.PlaneExtractor(480, 640, cfg)
+    assert str(e.value) == "Error! Invalid config parameter: patchSize(0). patchSize has to be positive."
+    with pytest.raises(RuntimeError) as e:
+        D.PlaneExtractor(480, 640).process(np.zeros((0, 3), np.float32))
+    assert str(e.value) == "Error! Number of points doesn't match image shape: 0 != 480 x 640"
+    with pytest.raises(RuntimeError) as e:
+        D.PlaneExtractor(240, 320).process(np.zeros((640 * 480, 3), np.float32))
+    assert str(e.value) == "Error! Number of points doesn't match image shape: 307200 != 240 x 320"
+    with pytest.raises(RuntimeError):
+        D.utils.DepthImage(str(synth.GOLDEN / "invalid" / "MissingParameters.ini"))  # not a PNG
+
+
+@pytest.mark.parametrize("h,w,batch,kw", [(240, 320, 8, {}), (480, 640, 6, {}), (480, 640, 4, {"noise": False}),
+                                          (480, 640, 4, {"scale": 5.0}), (960, 1280, 2, {})])
+def test_synthetic_batches_full_parity(D, oracle, h, w, batch, kw):
+    depth = synth.synth_batch(batch, h, w, seed0=0, **kw)
+    labels = full_compare(D, oracle, depth, synth.intrinsics_for(h, w), oracle.default_config())
+    tag = "_".join(f"{k}{v}" for k, v in kw.items()) or "noisy"
+    name = f"synth_{w}x{h}_{tag}_seed0"
+    if name in GOLD:
+        assert sha(labels[0]) == GOLD[name]["sha256"]  # committed golden (oracle, glibc flavour)
+
+
+@pytest.mark.parametrize("patch", [4, 5, 7, 8, 12, 16, 20, 3])
+def test_patch_sizes(D, oracle, patch):
+    """Static (4, 8, 10, 16) and runtime patch sizes, odd sizes (different Eigen alignment of the column sums) and
+    sizes that do not divide the image (sheared cell tiling, cell_grid.cpp:71)."""
+    depth = synth.synth_batch(2, 240, 320, seed0=3)
+    full_compare(D, oracle, depth, synth.intrinsics_for(240, 320), oracle.default_config(patch_size=patch))
+
+
+def test_config_variants(D, oracle):
+    depth = synth.synth_batch(2, 240, 320, seed0=5)
+    intr = synth.intrinsics_for(240, 320)
+    for ov in ({"min_region_growing_cells_activated": 1, "min_region_growing_candidate_size": 1},
+               {"min_pts_per_cell": 6}, {"histogram_bins_per_coord": 7}, {"max_number_depth_discontinuity": 3},
+               {"min_cos_angle_merge": 0.99, "max_merge_dist": 50.0}, {"min_region_planarity_score": 0.9},
+               {"min_region_growing_candidate_size": -1}, {"min_region_growing_cells_activated": -1}):
+        full_compare(D, oracle, depth, intr, oracle.default_config(**ov))
+
+
+def test_ragged_and_tiny_images(D, oracle):
+    for (h, w) in [(250, 330), (37, 53), (10, 10), (9, 200)]:
+        depth = synth.synth_batch(2, h, w, seed0=1)
+        full_compare(D, oracle, depth, synth.intrinsics_for(h, w), oracle.default_config())
+
+
+def test_global_state_variant(D, oracle):
+    """The region-growing kernel keeps its per-cell state in LDS when it fits and in global memory otherwise;
+    force the global variant on a small frame to check it."""
+    os.environ["DPX_FORCE_GLOBAL_STATE"] = "1"
+    try:
+        depth = synth.synth_batch(3, 240, 320, seed0=7)
+        full_compare(D, oracle, depth, synth.intrinsics_for(240, 320), oracle.default_config())
+        full_compare(D, oracle, synth.tum_stream(2), tuple(float(v) for v in np.array(synth.read_K(synth.TUM_K))[[0, 1, 0, 1], [0, 1, 2, 2]]),
+                     oracle.default_config())
+    finally:
+        del os.environ["DPX_FORCE_GLOBAL_STATE"]
+
+
+def test_tum_stream_batch64_properties(D, oracle):
+    """BASELINE.json configs[1] at full size: batch of 64 TUM-stream frames.  Size-independent properties plus a
+    checksum-of-checksums against the oracle on every frame."""
+    depth = synth.tum_stream(64)
+    K = synth.read_K(synth.TUM_K)
+    intr = tuple(float(v) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2]))
+    ex = D.PlaneExtractor(480, 640, max_batch=64)
+    a = ex.process_depth_batch(depth, *intr)
+    b = ex.process_depth_batch(depth, *intr)
+    assert np.array_equal(a, b)  # idempotent / deterministic
+    single = D.PlaneExtractor(480, 640).process_depth_batch(depth[17:18], *intr)
+    assert np.array_equal(single[0], a[17])  # batch independence
+    lab = a.reshape(64, 48, 10, 64, 10)
+    assert np.all(lab == lab[:, :, :1, :, :1])  # constant within every 10x10 cell
+    assert sha(a[0]) == GOLD["tum_f32_default"]["sha256"]
+    for k in range(4):
+        assert sha(a[k]) == GOLD[f"tum_stream_{k}"]["sha256"]
+    oracle.set_math("devmath")
+    ref = oracle.process_depth_batch(oracle.default_config(), depth, *intr, threads=min(16, os.cpu_count() or 1))
+    assert hashlib.sha256(b"".join(bytes.fromhex(sha(x)) for x in a)).hexdigest() == \
+           hashlib.sha256(b"".join(bytes.fromhex(sha(x)) for x in ref)).hexdigest()
+    for k in range(64):
+        assert a[k].max() <= ex.frame_stats(k)["segments"]
+
+
+def test_plane_parameters_vs_glibc_flavour(D, oracle):
+    """north_star: fitted plane parameters within 1e-5 of the reference semantics (oracle with glibc libm)."""
+    depth = synth.synth_batch(4, 480, 640, seed0=20)
+    intr = synth.intrinsics_for(480, 640)
+    ex = D.PlaneExtractor(480, 640, max_batch=4)
+    labels = ex.process_depth_batch(depth, *intr)
+    oracle.set_math("glibc")
+    for k in range(4):
+        ol, _, op, _, _ = oracle.process(oracle.default_config(), 480, 640, oracle.backproject(depth[k], *[np.float32(v) for v in intr]), debug=True)
+        assert np.array_equal(labels[k], ol)
+        gp = ex.planes(k)
+        assert len(gp) == len(op)
+        for f in ("normal", "d", "mean", "mse", "score"):
+            np.testing.assert_allclose(gp[f], op[f], rtol=1e-5, atol=1e-5)  # tolerance stated by north_star
+
+
+def test_devmath_and_eigensolver_on_device(D, oracle):
+    """dpx_math.h and the register eigensolver return the same bits on gfx950 as on the host."""
+    import ctypes as C
+    from deplex_amd import _capi
+    rng = np.random.default_rng(3)
+    n = 200000
+    L = _capi.lib()
+    OL = oracle.lib()
+
+    def dev(which, a, b=None):
+        out = np.empty_like(a)
+        _capi.check(L.dpx_test_math(which, a.ctypes.data, (b if b is not None else a).ctypes.data, out.ctypes.data, a.size, 0))
+        return out
+    # host results of the same header via the oracle's devmath flavour are not exported one by one; use ctypes on
+    # a tiny shim compiled in the build container?  Not available on the GPU box -> compare through eig3 + sqrt.
+    a = np.abs(rng.normal(size=n)) * 10 ** rng.uniform(-200, 200, size=n)
+    assert np.array_equal(dev(4, a).view(np.uint64), np.sqrt(a).view(np.uint64))  # IEEE sqrt
+    mats = []
+    for i in range(20000):
+        M = rng.normal(size=(3, 3)) * 10 ** rng.uniform(-3, 6)
+        A = M @ M.T
+        if i % 4 == 0:
+            p = (rng.normal(size=(100, 3)) * [1000, 1000, 10 ** rng.uniform(-6, -1)]).astype(np.float32).astype(np.float64)
+            A = np.cov(p.T) * 99
+        if i % 7 == 0:
+            A = np.diag(rng.uniform(0, 1e6, 3))
+        if i % 11 == 0:
+            A = np.round(A)
+        mats.append(A)
+    mats += [np.zeros((3, 3)), np.eye(3), np.ones((3, 3)), np.full((3, 3), np.nan), np.diag([1.0, 1.0, 2.0])]
+    A6 = np.array([[A[0, 0], A[0, 1], A[0, 2], A[1, 1], A[1, 2], A[2, 2]] for A in mats])
+    Q = np.empty((len(mats), 9)); w = np.empty((len(mats), 3)); rc = np.empty(len(mats), np.int32)
+    _capi.check(L.dpx_test_eig3(A6.ctypes.data, Q.ctypes.data, w.ctypes.data, rc.ctypes.data, len(mats), 0))
+    oracle.set_math("devmath")
+    nql = 0
+    for i, A in enumerate(mats):
+        orc, oQ, ow = oracle.eig3(A)
+        assert orc == rc[i]
+        nql += orc != 0
+        assert np.array_equal(oQ.reshape(-1).view(np.uint64), Q[i].view(np.uint64)), i
+        assert np.array_equal(ow.view(np.uint64), w[i].view(np.uint64)), i
+    assert nql > 100
+
+
+def test_device_pointer_api_with_torch(D, oracle):
+    """The stream-ordered device-pointer entry point fed from torch tensors (device memory + stream plumbing)."""
+    import torch
+    depth = synth.synth_batch(3, 240, 320, seed0=11)
+    intr = synth.intrinsics_for(240, 320)
+    dev = torch.device("cuda", 0)
+    d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
+    d_labels = torch.full((3, 240 * 320), -1, dtype=torch.int32, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    ex = D.PlaneExtractor(240, 320, max_batch=3)
+    ex.set_profiling(True)
+    torch.cuda.synchronize()
+    ex.process_depth_device(d_depth.data_ptr(), 3, *intr, d_labels.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    oracle.set_math("devmath")
+    ref = oracle.process_depth_batch(oracle.default_config(), depth, *intr)
+    assert np.array_equal(d_labels.cpu().numpy(), ref)
+    ms = ex.kernel_ms()
+    assert all(v >= 0 for v in ms.values()) and ms["planefit"] > 0
+    t = ex.time_planefit(d_depth.data_ptr(), 0, 3, *intr, 5, stream.cuda_stream)
+    assert t > 0 and ex.planefit_bytes(0, 3) == 3 * (240 * 320 * 2 + 32 * 24 * 64)

@@ -1,0 +1,115 @@
+"""Host-side checks that need no GPU: the C-ABI library loads and exports every symbol the header declares,
+Config mirrors the reference's defaults and .ini reader, and the product fails loudly without a device."""
+import re
+from pathlib import Path
+
+import pytest
+
+import synth
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_library_exports_every_declared_symbol():
+    from deplex_amd import _capi
+    header = (ROOT / "include" / "deplex_amd.h").read_text()
+    declared = set(re.findall(r"\b(dpx_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    L = _capi.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"libdeplex_amd.so does not export {name}"
+    assert declared == set(_capi.SYMBOLS), (declared ^ set(_capi.SYMBOLS))
+    assert b"gfx950" in L.dpx_version()
+
+
+def test_header_cites_reference_interfaces():
+    header = (ROOT / "include" / "deplex_amd.h").read_text()
+    for cite in ("plane_extractor.cpp:153-176", "plane_extractor.cpp:185-283", "config.cpp:28-80", "depth_image.cpp:55-78"):
+        assert cite in header
+
+
+def test_config_defaults_match_reference():
+    """cpp/deplex/include/deplex/config.h:51-81."""
+    import deplex_amd as D
+    c = D.Config()
+    assert (c.patch_size, c.histogram_bins_per_coord, c.min_region_growing_candidate_size,
+            c.min_region_growing_cells_activated, c.min_pts_per_cell, c.max_number_depth_discontinuity,
+            c.ransac_max_iterations) == (10, 20, 5, 4, 3, 1, 1000)
+    import numpy as np
+    f = np.float32
+    assert c.min_cos_angle_merge == f(0.90) and c.max_merge_dist == 500 and c.min_region_planarity_score == f(0.55)
+    assert c.depth_sigma_coeff == f(1.425e-6) and c.depth_sigma_margin == 10 and c.depth_discontinuity_threshold == 160
+    assert c.ransac_refinement is False and c.ransac_threshold == 1 and c.ransac_inliers_ratio == f(0.9)
+
+
+def test_config_ini_reader():
+    """cpp/tests/test_config.cpp:24-29 and config.cpp:28-80."""
+    import deplex_amd as D
+    with pytest.raises(D.DeplexError) as e:
+        D.Config("definitely/not/here.ini")
+    assert str(e.value) == "Couldn't open ini file: definitely/not/here.ini"
+    missing = D.Config(str(synth.GOLDEN / "invalid" / "MissingParameters.ini"))
+    d = D.Config()
+    for k in ("depth_sigma_coeff", "depth_sigma_margin", "min_pts_per_cell", "depth_discontinuity_threshold",
+              "max_number_depth_discontinuity", "patch_size"):
+        assert getattr(missing, k) == getattr(d, k)
+    icl = D.Config(str(synth.ICL_INI))
+    assert icl.patch_size == 4 and icl.min_region_planarity_score == 0.5 and abs(icl.ransac_inliers_ratio - 0.15) < 1e-7
+
+
+def test_config_ini_quirks(tmp_path):
+    """No trimming, '#' comments, lines without '=' skipped, std::stoi prefix parsing (stoi("1e6") == 1)."""
+    import deplex_amd as D
+    p = tmp_path / "q.ini"
+    p.write_text("# comment\n[Parameters]\npatchSize=1e6\n=5\nmaxMergeDist=12.5abc\n patchSize=3\nransacRefinement=0\n")
+    c = D.Config(str(p))
+    assert c.patch_size == 1 and c.max_merge_dist == 12.5
+    p.write_text("patchSize=abc\n")
+    with pytest.raises(D.DeplexError):
+        D.Config(str(p))
+
+
+def test_oracle_and_product_ini_agree(oracle):
+    import deplex_amd as D
+    for ini in (synth.ICL_INI, synth.TUM_INI, synth.GOLDEN / "invalid" / "MissingParameters.ini"):
+        a, b = D.Config(str(ini)), oracle.config_from_ini(ini)
+        for f, _ in b._fields_:
+            assert getattr(a._c, f) == getattr(b, f), (ini, f)
+
+
+def test_patch_size_zero_message_without_gpu():
+    """plane_extractor.cpp:161-164 — the message is produced before any device work."""
+    import deplex_amd as D
+    c = D.Config()
+    c.patch_size = 0
+    with pytest.raises(D.DeplexError) as e:
+        D.PlaneExtractor(480, 640, c)
+    assert e.value.code == -1
+    assert str(e.value) == "Error! Invalid config parameter: patchSize(0). patchSize has to be positive."
+
+
+def test_product_fails_loudly_without_gpu():
+    """No CPU fallback: without a HIP device construction raises instead of silently computing elsewhere."""
+    import ctypes as C
+    from deplex_amd import _capi
+    import deplex_amd as D
+    n = C.c_int(0)
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        rc = hip.hipGetDeviceCount(C.byref(n))
+        has_gpu = rc == 0 and n.value > 0
+    except OSError:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("a GPU is present")
+    with pytest.raises(D.DeplexError) as e:
+        D.PlaneExtractor(480, 640)
+    assert e.value.code == _capi.DPX_ERR_NO_DEVICE
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under deplex_amd/ may reference it."""
+    for p in (ROOT / "deplex_amd").rglob("*"):
+        if p.suffix in (".py", ".h", ".hip", ".cpp") and p.is_file():
+            txt = p.read_text(errors="ignore")
+            assert "oracle" not in txt.replace("(oracle, \"devmath\" flavour)", ""), p

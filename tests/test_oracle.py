@@ -1,0 +1,209 @@
+"""Pins the CPU oracle: the reference's own known-answer tests, the provisional goldens of SURVEY.md Appendix B,
+and the reference's compiled eigensolver (oracle/_ref).  CPU only."""
+import hashlib
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import synth
+
+GOLD = json.loads((Path(__file__).parent / "golden" / "oracle_goldens.json").read_text())
+ROWS = {r["name"]: r for r in GOLD["rows"]}
+# sha256 prefixes derived independently of this oracle (NumPy restatement + reference dsyev)
+APPENDIX_B = {"tum_f32_default": "39ebeb6b74980ee987ad629e835b9d29de9daf4000a4fe5cec1f60441f0c8500",
+              "tum_f64_default": "2bd10492d27d740f", "icl_default": "02576a9cf2bf4a14", "icl_ini": "eae45aa7663b36c3"}
+
+
+def sha(labels):
+    return hashlib.sha256(labels.astype("<i4").tobytes()).hexdigest()
+
+
+def tum_cloud(oracle, tum_depth):
+    K = synth.read_K(synth.TUM_K)
+    return oracle.backproject(tum_depth, K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+
+
+def f64_cloud(depth, kpath):
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
+    from make_goldens import f64_backproject
+    return f64_backproject(depth, kpath)
+
+
+@pytest.mark.parametrize("flavour", ["glibc", "devmath"])
+def test_tum_default_config_extraction_34(oracle, tum_depth, flavour):
+    """cpp/tests/test_plane_extractor.cpp:27-33 — labels.maxCoeff() == 34."""
+    oracle.set_math(flavour)
+    labels = oracle.process(oracle.default_config(), 480, 640, tum_cloud(oracle, tum_depth))
+    assert labels.max() == 34
+    assert labels.size == 480 * 640
+    assert sha(labels) == APPENDIX_B["tum_f32_default"]
+
+
+@pytest.mark.parametrize("flavour", ["glibc", "devmath"])
+def test_tum_python_path_34(oracle, tum_depth, flavour):
+    """python/tests/test_plane_extraction.py:44-52 — float64 back-projection, 34 planes, label count == N."""
+    oracle.set_math(flavour)
+    pts = f64_cloud(tum_depth, synth.TUM_K)
+    labels = oracle.process(oracle.default_config(), 480, 640, pts)
+    assert labels.max() == 34 and labels.size == pts.shape[0]
+    assert sha(labels).startswith(APPENDIX_B["tum_f64_default"])
+
+
+@pytest.mark.parametrize("flavour", ["glibc", "devmath"])
+def test_icl_goldens(oracle, icl_depth, flavour):
+    oracle.set_math(flavour)
+    K = synth.read_K(synth.ICL_K)
+    xyz = oracle.backproject(icl_depth, K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+    l1, _, _, _, st1 = oracle.process(oracle.default_config(), 480, 640, xyz, debug=True)
+    l2, _, _, _, st2 = oracle.process(oracle.config_from_ini(synth.ICL_INI), 480, 640, xyz, debug=True)
+    assert sha(l1).startswith(APPENDIX_B["icl_default"]) and st1["segments"] == 18 and st1["planar_cells"] == 2785
+    assert sha(l2).startswith(APPENDIX_B["icl_ini"]) and st2["segments"] == 45 and st2["planar_cells"] == 18527
+    assert int((l2 > 0).sum()) == 294032 and st2["activations"] == 18387 and st2["max_grow"] == 8144
+    assert st2["ql_fallbacks"] == 571  # QL fallback rate measured on the reference's own dsyev
+
+
+def test_zero_leading_config(oracle, tum_depth):
+    """test_plane_extractor.cpp:35-45 — min_region_planarity_score = 5000 -> all-zero labels."""
+    cfg = oracle.config_from_ini(synth.TUM_INI)
+    cfg.min_region_planarity_score = 5000
+    labels = oracle.process(cfg, 480, 640, tum_cloud(oracle, tum_depth))
+    assert not labels.any() and labels.size == 480 * 640
+
+
+def test_zero_patch_size_throws(oracle, tum_depth):
+    """test_plane_extractor.cpp:47-53."""
+    cfg = oracle.config_from_ini(synth.TUM_INI)
+    cfg.patch_size = 0
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.process(cfg, 480, 640, tum_cloud(oracle, tum_depth))
+    assert e.value.code == -1
+    assert str(e.value) == "Error! Invalid config parameter: patchSize(0). patchSize has to be positive."
+
+
+def test_enormous_patch_size(oracle, tum_depth):
+    """test_plane_extractor.cpp:55-65 — patch_size = 1e6 -> zero cells -> all-zero labels."""
+    cfg = oracle.config_from_ini(synth.TUM_INI)
+    cfg.patch_size = int(1e6)
+    labels = oracle.process(cfg, 480, 640, tum_cloud(oracle, tum_depth))
+    assert not labels.any() and labels.size == 480 * 640
+
+
+def test_zero_value_points(oracle):
+    """test_plane_extractor.cpp:67-74."""
+    labels = oracle.process(oracle.default_config(), 480, 640, np.zeros((640 * 480, 3), np.float32))
+    assert not labels.any() and labels.size == 640 * 480
+
+
+def test_empty_and_wrong_shape_throw(oracle):
+    """test_plane_extractor.cpp:76-88."""
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.process(oracle.default_config(), 480, 640, np.zeros((0, 3), np.float32))
+    assert e.value.code == -2 and str(e.value) == "Error! Number of points doesn't match image shape: 0 != 480 x 640"
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.process(oracle.default_config(), 240, 320, np.zeros((640 * 480, 3), np.float32))
+    assert str(e.value) == "Error! Number of points doesn't match image shape: 307200 != 240 x 320"
+
+
+def test_depth_image_transform(oracle, tum_depth):
+    """cpp/tests/test_depth_image.cpp:24-48 — 640x480, max z 46655, min z 0."""
+    assert tum_depth.shape == (480, 640)
+    xyz = tum_cloud(oracle, tum_depth)
+    assert xyz[:, 2].max() == 46655 and xyz[:, 2].min() == 0
+    assert int(tum_depth.astype(np.int64).sum()) == 3256065663  # stb_image == Pillow decode
+
+
+def test_config_ini(oracle):
+    """cpp/tests/test_config.cpp:24-29 — commented-out keys keep their defaults."""
+    cfg = oracle.config_from_ini(synth.GOLDEN / "invalid" / "MissingParameters.ini")
+    d = oracle.default_config()
+    for f, _ in cfg._fields_:
+        assert getattr(cfg, f) == getattr(d, f), f
+    icl = oracle.config_from_ini(synth.ICL_INI)
+    assert icl.patch_size == 4 and abs(icl.min_cos_angle_merge - 0.93) < 1e-6 and icl.min_region_planarity_score == 0.5
+
+
+def test_committed_goldens_reproduce(oracle):
+    """Every row of tests/golden/oracle_goldens.json that is cheap to regenerate is regenerated and compared."""
+    oracle.set_math("glibc")
+    Kt = synth.read_K(synth.TUM_K)
+    ts = synth.tum_stream(4)
+    for k in range(4):
+        r = ROWS[f"tum_stream_{k}"]
+        assert hashlib.sha256(ts[k].tobytes()).hexdigest() == r["depth_sha256"]
+        xyz = oracle.backproject(ts[k], Kt[0, 0], Kt[1, 1], Kt[0, 2], Kt[1, 2])
+        assert sha(oracle.process(oracle.default_config(), 480, 640, xyz)) == r["sha256"]
+    for s in range(4):
+        r = ROWS[f"synth_320x240_noisy_seed{s}"]
+        d = synth.synth_depth(240, 320, seed=s)
+        assert hashlib.sha256(d.tobytes()).hexdigest() == r["depth_sha256"], "synthetic generator drifted"
+        fx, fy, cx, cy = synth.intrinsics_for(240, 320)
+        l, _, _, _, st = oracle.process(oracle.default_config(), 240, 320, oracle.backproject(d, fx, fy, cx, cy), debug=True)
+        assert sha(l) == r["sha256"] and st["segments"] == r["segments"]
+
+
+def test_math_flavours_agree_on_labels(oracle):
+    """glibc (what the reference links) vs dpx_math.h (what the device runs): identical label maps and plane
+    parameters within 1e-5 on seeded synthetic frames; per-cell float fields may differ in the last bit."""
+    fx, fy, cx, cy = synth.intrinsics_for(480, 640)
+    ulp_cells = 0
+    total = 0
+    for s in range(3):
+        for kw in ({}, {"noise": False}):
+            d = synth.synth_depth(480, 640, seed=s, **kw)
+            xyz = oracle.backproject(d, fx, fy, cx, cy)
+            oracle.set_math("glibc")
+            l0, c0, p0, _, _ = oracle.process(oracle.default_config(), 480, 640, xyz, debug=True)
+            oracle.set_math("devmath")
+            l1, c1, p1, _, _ = oracle.process(oracle.default_config(), 480, 640, xyz, debug=True)
+            assert np.array_equal(l0, l1)
+            assert len(p0) == len(p1)
+            for f in ("normal", "d", "mse", "score", "mean"):
+                np.testing.assert_allclose(p1[f], p0[f], rtol=1e-5, atol=1e-5)
+            v = c0["valid"].astype(bool)
+            assert np.array_equal(c0["planar"], c1["planar"]) and np.array_equal(c0["bin"], c1["bin"])
+            ulp_cells += int((c0["mse"][v].view(np.uint32) != c1["mse"][v].view(np.uint32)).sum())
+            total += int(v.sum())
+    assert ulp_cells <= total * 0.01  # rare last-bit differences only
+
+
+def test_eigensolver_matches_reference_dsyev(oracle):
+    """oracle/_ref/libdsyev_ref.so is the reference's own libs/dsyev compiled by oracle/Makefile: the oracle's
+    restatement must return the same bits (eigenvalues, eigenvectors, analytic/QL path)."""
+    if oracle.ref_dsyevh3(np.eye(3)) is None:
+        pytest.skip("oracle/_ref not built (reference checkout absent)")
+    oracle.set_math("glibc")
+    rng = np.random.default_rng(7)
+    ql = 0
+    mats = [np.zeros((3, 3)), np.eye(3), np.ones((3, 3)), np.diag([1.0, 1.0, 2.0]), np.diag([3.0, 2.0, 1.0])]
+    for i in range(6000):
+        M = rng.normal(size=(3, 3)) * 10 ** rng.uniform(-3, 6)
+        A = M @ M.T
+        if i % 4 == 0:  # nearly planar point sets, like cell covariances
+            p = (rng.normal(size=(100, 3)) * [1000, 1000, 10 ** rng.uniform(-6, -1)]).astype(np.float32).astype(np.float64)
+            A = np.cov(p.T) * 99
+        if i % 7 == 0:
+            A = np.diag(rng.uniform(0, 1e6, 3))
+        if i % 11 == 0:
+            A = np.round(A)
+        if i % 13 == 0:
+            A[0, 1] = A[1, 0] = 0
+        mats.append(A)
+    for A in mats:
+        rc, Q, w = oracle.eig3(A)
+        rrc, rQ, rw = oracle.ref_dsyevh3(A.copy())
+        ql += rc != 0
+        assert np.array_equal(Q.view(np.uint64), rQ.view(np.uint64)) and np.array_equal(w.view(np.uint64), rw.view(np.uint64))
+    assert ql > 100  # the QL fallback is exercised
+
+
+def test_frame_parallel_batch_matches_single(oracle):
+    d = synth.synth_batch(6, 240, 320, seed0=10)
+    fx, fy, cx, cy = synth.intrinsics_for(240, 320)
+    a = oracle.process_depth_batch(oracle.default_config(), d, fx, fy, cx, cy, threads=1)
+    b = oracle.process_depth_batch(oracle.default_config(), d, fx, fy, cx, cy, threads=3)
+    assert np.array_equal(a, b)
+    single = oracle.process(oracle.default_config(), 240, 320, oracle.backproject(d[2], fx, fy, cx, cy))
+    assert np.array_equal(a[2], single)
