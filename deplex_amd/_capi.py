@@ -69,6 +69,7 @@ SYMBOLS = {
     "dpx_process_depth_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "dpx_process_depth_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "dpx_process_pcd_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "dpx_prepare_intrinsics": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_int32)]),
     "dpx_backproject": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int32]),
     "dpx_grid_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "dpx_get_cells": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),

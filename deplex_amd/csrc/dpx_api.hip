@@ -13,6 +13,7 @@
 
 #include "../../include/deplex_amd.h"
 #include "dpx_kernels.h"
+#include "dpx_planefit_fast.h"
 #include "dpx_regions.h"
 
 namespace {
@@ -64,6 +65,10 @@ struct dpx_handle_s {
   size_t d_in_bytes = 0;
   int32_t* d_labels = nullptr;
   size_t d_labels_bytes = 0;
+  // exact-division-by-reciprocal verification cache (dpx_planefit_fast.h)
+  bool fd_valid = false, fd_ok = false;
+  float fd_fx = 0, fd_fy = 0, fd_cx = 0, fd_cy = 0, fd_rx = 0, fd_ry = 0;
+  unsigned int* d_mismatch = nullptr;
   // profiling: a ring of event sets, one per process call
   bool profiling = false;
   static constexpr int kProfSlots = 128;
@@ -99,11 +104,52 @@ void free_all(dpx_handle h) {
   hipFree(h->d_gqueue);
   hipFree(h->d_in);
   hipFree(h->d_labels);
+  hipFree(h->d_mismatch);
   for (auto& slot : h->ev)
     for (auto& e : slot)
       if (e) hipEventDestroy(e);
   if (h->stream) hipStreamDestroy(h->stream);
 }
+
+bool fast_shape(const dpx::Params& prm) {
+  return !prm.sheared && (prm.P == 4 || prm.P == 8 || prm.P == 10) && (prm.W % 2 == 0) && prm.C > 0;
+}
+
+// Verifies (once per intrinsics tuple) that the reciprocal-based division of the fast plane-fit kernel returns the
+// IEEE quotient for every numerator this image geometry can produce.  Synchronises on first use.
+int prepare_intrinsics(dpx_handle h, float fx, float fy, float cx, float cy) {
+  if (h->fd_valid && h->fd_fx == fx && h->fd_fy == fy && h->fd_cx == cx && h->fd_cy == cy) return DPX_OK;
+  h->fd_valid = false;
+  h->fd_ok = false;
+  h->fd_rx = 1.0f / fx;
+  h->fd_ry = 1.0f / fy;
+  if (fast_shape(h->prm) && std::isfinite(h->fd_rx) && std::isfinite(h->fd_ry) && !std::getenv("DPX_NO_FASTDIV")) {
+    if (!h->d_mismatch) DPX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_mismatch), sizeof(unsigned int)));
+    DPX_HIP(hipMemsetAsync(h->d_mismatch, 0, sizeof(unsigned int), h->stream));
+    const long long tx = static_cast<long long>(h->W) * 65536, ty = static_cast<long long>(h->H) * 65536;
+    hipLaunchKernelGGL(dpx::k_verify_fastdiv, dim3(static_cast<unsigned>((tx + 255) / 256)), dim3(256), 0, h->stream, h->W, cx, fx, h->fd_rx, h->d_mismatch);
+    hipLaunchKernelGGL(dpx::k_verify_fastdiv, dim3(static_cast<unsigned>((ty + 255) / 256)), dim3(256), 0, h->stream, h->H, cy, fy, h->fd_ry, h->d_mismatch);
+    unsigned int mism = 1;
+    DPX_HIP(hipMemcpyAsync(&mism, h->d_mismatch, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+    DPX_HIP(hipStreamSynchronize(h->stream));
+    h->fd_ok = (mism == 0);
+  }
+  h->fd_fx = fx; h->fd_fy = fy; h->fd_cx = cx; h->fd_cy = cy;
+  h->fd_valid = true;
+  return DPX_OK;
+}
+
+template <int P>
+void launch_planefit_fast(const dpx::Params& prm, const void* d_in, dpx_cell* d_cells, hipStream_t s, bool fastdiv, float rx, float ry) {
+  const long long waves = static_cast<long long>(prm.batch) * prm.nv * ((prm.nh + 63) / 64);
+  const unsigned blocks = static_cast<unsigned>((waves + 3) / 4);
+  if (fastdiv)
+    hipLaunchKernelGGL((dpx::k_planefit_depth<P, true>), dim3(blocks), dim3(256), 0, s, prm, static_cast<const uint16_t*>(d_in), d_cells, rx, ry);
+  else
+    hipLaunchKernelGGL((dpx::k_planefit_depth<P, false>), dim3(blocks), dim3(256), 0, s, prm, static_cast<const uint16_t*>(d_in), d_cells, rx, ry);
+}
+
+void launch_planefit_depth(dpx_handle h, const dpx::Params& prm, const void* d_in, hipStream_t s);
 
 template <bool DEPTH>
 void launch_planefit(const dpx::Params& prm, const void* d_in, dpx_cell* d_cells, hipStream_t s) {
@@ -119,6 +165,19 @@ void launch_planefit(const dpx::Params& prm, const void* d_in, dpx_cell* d_cells
   }
 }
 
+void launch_planefit_depth(dpx_handle h, const dpx::Params& prm, const void* d_in, hipStream_t s) {
+  const char* v1 = std::getenv("DPX_PLANEFIT_V1");
+  if (fast_shape(prm) && !(v1 && v1[0] == '1')) {
+    switch (prm.P) {
+      case 4: launch_planefit_fast<4>(prm, d_in, h->d_cells, s, h->fd_ok, h->fd_rx, h->fd_ry); return;
+      case 8: launch_planefit_fast<8>(prm, d_in, h->d_cells, s, h->fd_ok, h->fd_rx, h->fd_ry); return;
+      case 10: launch_planefit_fast<10>(prm, d_in, h->d_cells, s, h->fd_ok, h->fd_rx, h->fd_ry); return;
+      default: break;
+    }
+  }
+  launch_planefit<true>(prm, d_in, h->d_cells, s);
+}
+
 int run_pipeline(dpx_handle h, const void* d_in, bool depth, int batch, float fx, float fy, float cx, float cy,
                  int32_t* d_labels, hipStream_t s) {
   if (batch < 0 || batch > h->max_batch)
@@ -127,6 +186,10 @@ int run_pipeline(dpx_handle h, const void* d_in, bool depth, int batch, float fx
   h->last_stream = s;
   h->last_batch = batch;
   if (batch == 0) return DPX_OK;
+  if (depth) {
+    const int rcp = prepare_intrinsics(h, fx, fy, cx, cy);
+    if (rcp) return rcp;
+  }
   dpx::Params prm = h->prm;
   prm.batch = batch;
   prm.fx = fx; prm.fy = fy; prm.cx = cx; prm.cy = cy;
@@ -135,7 +198,7 @@ int run_pipeline(dpx_handle h, const void* d_in, bool depth, int batch, float fx
   if (prof) DPX_HIP(hipEventRecord(ev[0], s));
   if (prm.C > 0) {
     if (depth)
-      launch_planefit<true>(prm, d_in, h->d_cells, s);
+      launch_planefit_depth(h, prm, d_in, s);
     else
       launch_planefit<false>(prm, d_in, h->d_cells, s);
   }
@@ -535,6 +598,14 @@ int dpx_get_planes(dpx_handle h, int32_t frame, dpx_plane* out, int32_t cap, int
   return DPX_OK;
 }
 
+int dpx_prepare_intrinsics(dpx_handle h, float fx, float fy, float cx, float cy, int32_t* fast_division) {
+  if (!h) return fail(DPX_ERR_ARG, "null handle");
+  DPX_HIP(hipSetDevice(h->device));
+  const int rc = prepare_intrinsics(h, fx, fy, cx, cy);
+  if (rc == DPX_OK && fast_division) *fast_division = h->fd_ok ? 1 : 0;
+  return rc;
+}
+
 int dpx_set_profiling(dpx_handle h, int32_t enable) {
   if (!h) return fail(DPX_ERR_ARG, "null handle");
   DPX_HIP(hipSetDevice(h->device));
@@ -579,9 +650,13 @@ int dpx_time_planefit(dpx_handle h, const void* d_in, int32_t input_kind, int32_
   DPX_HIP(hipEventCreate(&a));
   DPX_HIP(hipEventCreate(&b));
   DPX_HIP(hipEventRecord(a, s));
+  if (input_kind == 0) {
+    const int rcp = prepare_intrinsics(h, fx, fy, cx, cy);
+    if (rcp) return rcp;
+  }
   for (int i = 0; i < iters; ++i) {
     if (input_kind == 0)
-      launch_planefit<true>(prm, d_in, h->d_cells, s);
+      launch_planefit_depth(h, prm, d_in, s);
     else
       launch_planefit<false>(prm, d_in, h->d_cells, s);
   }

@@ -145,6 +145,65 @@ struct ColSum8 {
   }
 };
 
+// Everything after the moments: plane fit, planarity, merge tolerance, histogram bin, record.
+// (dx, dy, dz) = first point - last point of the cell (cell_segment.cpp:107).
+__device__ __forceinline__ void finish_cell(const Params& prm, int n, const float sum[3], const float pp[6], float dx,
+                                            float dy, float dz, bool valid, dpx_cell& out) {
+  PlaneFit fit;
+  fit_plane(sum, pp, n, fit);
+
+  // hasSmallPlaneError (cell_segment.cpp:99-102)
+  const float mz = fit.mean[2];
+  const float thr = prm.sigma_coeff * (mz * mz) + prm.sigma_margin;
+  const bool planar = valid && (static_cast<double>(fit.mse) <= static_cast<double>(thr) * static_cast<double>(thr));
+  // calculateMergeTolerance (cell_segment.cpp:104-110), min_merge_dist 20
+  const float diam = __builtin_sqrtf(dx * dx + (dy * dy + dz * dz));
+  float t = diam * prm.tol_sin;
+  t = (t < 20.0f) ? 20.0f : t;                      // std::max(t, 20)
+  t = (prm.max_merge_dist < t) ? prm.max_merge_dist : t;  // std::min(t, max)
+  const float tol = t * t;
+
+  // histogram bin (normals_histogram.cpp:32-45), planar cells only (plane_extractor.cpp:286-291)
+  uint32_t bin1 = 0;
+  if (planar) {
+    const float nx = fit.normal[0], ny = fit.normal[1], nz = fit.normal[2];
+    const bool is_zero = __builtin_fabsf(nx) <= 1e-5f && __builtin_fabsf(ny) <= 1e-5f && __builtin_fabsf(nz) <= 1e-5f;
+    if (!is_zero) {
+      const double dnx = nx, dny = ny;
+      const double proj = dpxm::dsqrt(dnx * dnx + dny * dny);
+      const double polar = dpxm::dacos(static_cast<double>(-nz));
+      const double azim = dpxm::datan2(dnx / proj, dny / proj);
+      const double kPi = 3.14159265358979323846;
+      const int B = prm.hist_B;
+      const int Xq = static_cast<int>((B - 1) * (polar - 0.0) / (kPi - 0.0));
+      int Yq = 0;
+      // azim is NaN only when nx == ny == 0; the reference then has Xq == 0 (normal (0,0,-1)) and never
+      // evaluates Yq, or reads out of bounds for a (0,0,+1) normal (undefined there; defined as 0 here).
+      if (Xq > 0 && azim == azim) Yq = static_cast<int>((B - 1) * (azim - (-kPi)) / (kPi - (-kPi)));
+      bin1 = static_cast<uint32_t>(Yq * B + Xq) + 1u;
+    }
+  }
+
+  if (valid) {
+    out.sum[0] = sum[0]; out.sum[1] = sum[1]; out.sum[2] = sum[2];
+    out.pp[0] = pp[0]; out.pp[1] = pp[1]; out.pp[2] = pp[2]; out.pp[3] = pp[3]; out.pp[4] = pp[4]; out.pp[5] = pp[5];
+    out.normal[0] = fit.normal[0]; out.normal[1] = fit.normal[1]; out.normal[2] = fit.normal[2];
+    out.d = fit.d;
+    out.mse = fit.mse;
+    out.tol = tol;
+    out.info = CELL_VALID | (planar ? CELL_PLANAR : 0u) | (fit.path != 0 ? CELL_QL : 0u) | (bin1 << 8);
+  } else {
+    // reference leaves the default-constructed stat (mse = FLT_MAX, score 0) — cell_segment_stat.cpp:27
+    out.sum[0] = out.sum[1] = out.sum[2] = 0.f;
+    out.pp[0] = out.pp[1] = out.pp[2] = out.pp[3] = out.pp[4] = out.pp[5] = 0.f;
+    out.normal[0] = out.normal[1] = out.normal[2] = 0.f;
+    out.d = 0.f;
+    out.mse = 3.402823466e+38f;
+    out.tol = 0.f;
+    out.info = 0u;
+  }
+}
+
 // One cell: everything CellSegment::CellSegment does (cell_segment.cpp:21-35) plus the histogram bin.
 template <int PT, bool DEPTH>
 __device__ __forceinline__ void planefit_cell(const Params& prm, const PointSrc<DEPTH>& src, int cr, int cc,
@@ -260,61 +319,7 @@ __device__ __forceinline__ void planefit_cell(const Params& prm, const PointSrc<
   }
 
   const bool valid = prm.valid_thr >= 0 && static_cast<long long>(valid_pts) >= prm.valid_thr && cont;
-
-  PlaneFit fit;
-  fit_plane(sum, pp, n, fit);
-
-  // hasSmallPlaneError (cell_segment.cpp:99-102)
-  const float mz = fit.mean[2];
-  const float thr = prm.sigma_coeff * (mz * mz) + prm.sigma_margin;
-  const bool planar = valid && (static_cast<double>(fit.mse) <= static_cast<double>(thr) * static_cast<double>(thr));
-  // calculateMergeTolerance (cell_segment.cpp:104-110), min_merge_dist 20
-  const float dx = fx0 - lx, dy = fy0 - ly, dz = fz0 - lz;
-  const float diam = __builtin_sqrtf(dx * dx + (dy * dy + dz * dz));
-  float t = diam * prm.tol_sin;
-  t = (t < 20.0f) ? 20.0f : t;                      // std::max(t, 20)
-  t = (prm.max_merge_dist < t) ? prm.max_merge_dist : t;  // std::min(t, max)
-  const float tol = t * t;
-
-  // histogram bin (normals_histogram.cpp:32-45), planar cells only (plane_extractor.cpp:286-291)
-  uint32_t bin1 = 0;
-  if (planar) {
-    const float nx = fit.normal[0], ny = fit.normal[1], nz = fit.normal[2];
-    const bool is_zero = __builtin_fabsf(nx) <= 1e-5f && __builtin_fabsf(ny) <= 1e-5f && __builtin_fabsf(nz) <= 1e-5f;
-    if (!is_zero) {
-      const double dnx = nx, dny = ny;
-      const double proj = dpxm::dsqrt(dnx * dnx + dny * dny);
-      const double polar = dpxm::dacos(static_cast<double>(-nz));
-      const double azim = dpxm::datan2(dnx / proj, dny / proj);
-      const double kPi = 3.14159265358979323846;
-      const int B = prm.hist_B;
-      const int Xq = static_cast<int>((B - 1) * (polar - 0.0) / (kPi - 0.0));
-      int Yq = 0;
-      // azim is NaN only when nx == ny == 0; the reference then has Xq == 0 (normal (0,0,-1)) and never
-      // evaluates Yq, or reads out of bounds for a (0,0,+1) normal (undefined there; defined as 0 here).
-      if (Xq > 0 && azim == azim) Yq = static_cast<int>((B - 1) * (azim - (-kPi)) / (kPi - (-kPi)));
-      bin1 = static_cast<uint32_t>(Yq * B + Xq) + 1u;
-    }
-  }
-
-  if (valid) {
-    out.sum[0] = sum[0]; out.sum[1] = sum[1]; out.sum[2] = sum[2];
-    out.pp[0] = pp[0]; out.pp[1] = pp[1]; out.pp[2] = pp[2]; out.pp[3] = pp[3]; out.pp[4] = pp[4]; out.pp[5] = pp[5];
-    out.normal[0] = fit.normal[0]; out.normal[1] = fit.normal[1]; out.normal[2] = fit.normal[2];
-    out.d = fit.d;
-    out.mse = fit.mse;
-    out.tol = tol;
-    out.info = CELL_VALID | (planar ? CELL_PLANAR : 0u) | (fit.path != 0 ? CELL_QL : 0u) | (bin1 << 8);
-  } else {
-    // reference leaves the default-constructed stat (mse = FLT_MAX, score 0) — cell_segment_stat.cpp:27
-    out.sum[0] = out.sum[1] = out.sum[2] = 0.f;
-    out.pp[0] = out.pp[1] = out.pp[2] = out.pp[3] = out.pp[4] = out.pp[5] = 0.f;
-    out.normal[0] = out.normal[1] = out.normal[2] = 0.f;
-    out.d = 0.f;
-    out.mse = 3.402823466e+38f;
-    out.tol = 0.f;
-    out.info = 0u;
-  }
+  finish_cell(prm, n, sum, pp, fx0 - lx, fy0 - ly, fz0 - lz, valid, out);
 }
 
 // v1 launch shape: one thread per cell, 256-thread blocks over batch*C cells.

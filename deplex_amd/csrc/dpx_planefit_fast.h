@@ -1,0 +1,301 @@
+// dpx_planefit_fast.h — the tuned depth-input plane-fit kernel (K1+K2) for even patch sizes on images whose
+// width is a multiple of the patch (every BASELINE config).
+//
+// Mapping: one lane = one cell, one wavefront = 64 horizontally adjacent cells of one cell row.  A cell's row of
+// P uint16 depths is P*2 contiguous bytes and the next lane's cell starts right after it, so the per-lane row
+// loads (dwordx4 + dword for P = 10) of a wavefront cover one contiguous span of the image row: fully coalesced
+// HBM reads with no staging; every 128-byte line is fetched once.  The lane then owns all P*P points of its cell
+// in registers and runs the reference's exact float32 chains:
+//   sum_j     8 residue-class chains + pairwise fold + horizontal add   (Eigen packet redux order)
+//   sum p p^T 6 strictly sequential mul-then-add chains                  (Eigen GEMM scalar tail)
+// followed by the 3x3 eigen plane fit in f64 (dpx_fit.h) — all in registers, one 64-byte record out.
+//
+// Back-projection x = ((col - cx) * z) / fx needs two IEEE float divisions per pixel, which cost ~18 VALU issue
+// slots each on gfx950 (measured, tools/ubench/valu.hip).  Dividing by the constant fx is done instead as
+//   q = a * r;  e = fma(-q, fx, a);  x = fma(e, r, q)        with r = RN(1 / fx)
+// (3 issue slots).  That sequence is NOT assumed to be correctly rounded: dpx_verify_fastdiv (k_verify_fastdiv
+// below) checks it against the IEEE quotient for EVERY numerator the frame geometry can produce
+// ((col - cx) * z for all columns and all 65536 depths, same for rows) when intrinsics are first seen; if any
+// quotient differs the kernel is instantiated with IEEE division instead (FASTDIV = false).  The only remaining
+// difference is the sign of a zero quotient (z == 0 with a negative numerator gives +0 instead of -0); it can
+// influence a result only when every x (or y) of a cell is a zero, i.e. the whole cell has z == 0, and is
+// patched in closed form there (sum of signed zeros = -0 iff all terms are -0).
+#pragma once
+#include <utility>
+
+#include "dpx_kernels.h"
+
+namespace dpx {
+
+#ifndef DPX_PF_WAVES
+#define DPX_PF_WAVES 4
+#endif
+typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x2a __attribute__((ext_vector_type(2), aligned(4)));
+
+template <bool FASTDIV>
+__device__ __forceinline__ float div_const(float a, float b, float r) {
+  if (FASTDIV) {
+    const float q = a * r;
+    const float e = __builtin_fmaf(-q, b, a);
+    return __builtin_fmaf(e, r, q);
+  }
+  return a / b;
+}
+
+// Exhaustive check of div_const<true> against IEEE division for numerators (idx - c) * z, idx in [0, count),
+// z in [0, 65535].  mismatches[0] counts quotients that differ (as values; +0 == -0).
+__global__ __launch_bounds__(256) void k_verify_fastdiv(int count, float c, float b, float r, unsigned int* mismatches) {
+  const long long gid = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  const long long total = static_cast<long long>(count) * 65536;
+  if (gid >= total) return;
+  const int idx = static_cast<int>(gid >> 16);
+  const float z = static_cast<float>(static_cast<int>(gid & 0xFFFF));
+  const float a = (static_cast<float>(idx) - c) * z;
+  const float fast = div_const<true>(a, b, r);
+  const float ieee = a / b;
+  const bool same = (fast == ieee) || (fast != fast && ieee != ieee);
+  if (!same) atomicAdd(mismatches, 1u);
+}
+
+// Chain accumulator for the 8 residue classes, initialised to -0.0f so that the first element
+// can be ADDED ((-0) + v == v bit for bit, signed zeros included) and no first-touch special case is needed.
+struct Chains8 {
+  float c[8];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) c[m] = -0.0f;
+  }
+  __device__ __forceinline__ void fold() {
+    c[0] = c[0] + c[4];
+    c[1] = c[1] + c[5];
+    c[2] = c[2] + c[6];
+    c[3] = c[3] + c[7];
+  }
+};
+
+template <int P, bool FASTDIV>
+struct CellAcc {
+  static constexpr int n = P * P;
+  static constexpr int A2 = (n / 8) * 8;
+  Chains8 sx, sy, sz;
+  float xx, xy, xz, yy, yz, zz;
+  float fx0, fy0, fz0, lx, ly, lz;
+  float hprev, vprev;
+  int hdisc, vdisc, valid_pts;
+  bool folded;
+
+  __device__ __forceinline__ void init() {
+    sx.init(); sy.init(); sz.init();
+    xx = xy = xz = yy = yz = zz = 0.f;
+    fx0 = fy0 = fz0 = lx = ly = lz = 0.f;
+    hprev = vprev = 0.f;
+    hdisc = vdisc = valid_pts = 0;
+    folded = false;
+  }
+
+  // One pixel.  KM = k & 7 and the position flags are compile-time; the row index may be a runtime value.
+  template <int J, int KM, bool TAIL, int TAILIDX, bool FIRST, bool LAST, bool HROW>
+  __device__ __forceinline__ void pixel(uint32_t zi, float cx_j, float cy_i, const Params& prm, float rx, float ry) {
+    const float z = static_cast<float>(zi);
+    const float x = div_const<FASTDIV>(cx_j * z, prm.fx, rx);
+    const float y = div_const<FASTDIV>(cy_i * z, prm.fy, ry);
+    valid_pts += zi != 0u;
+    if (FIRST) { fx0 = x; fy0 = y; fz0 = z; }
+    if (LAST) { lx = x; ly = y; lz = z; }
+    if (HROW) {  // centre row, in j order (cell_segment.cpp:62-76)
+      if (J == 0) hprev = z;
+      if (z > 0 && __builtin_fabsf(z - hprev) < prm.disc_thr) hprev = z;
+      else if (z > 0) ++hdisc;
+    }
+    if (J == P / 2) {  // centre column, in i order (cell_segment.cpp:78-91); vprev is preset to the row-0 value
+      if (z > 0 && __builtin_fabsf(z - vprev) < prm.disc_thr) vprev = z;
+      else if (z > 0) ++vdisc;
+    }
+    if (!TAIL) {
+      sx.c[KM] = sx.c[KM] + x;
+      sy.c[KM] = sy.c[KM] + y;
+      sz.c[KM] = sz.c[KM] + z;
+    } else {  // trailing 4-packet after the 8-wide part: fold first, then add to chains 0..3
+      if (TAILIDX == 0 && A2 > 0) { sx.fold(); sy.fold(); sz.fold(); }
+      sx.c[TAILIDX] = sx.c[TAILIDX] + x;
+      sy.c[TAILIDX] = sy.c[TAILIDX] + y;
+      sz.c[TAILIDX] = sz.c[TAILIDX] + z;
+    }
+    if (n + 6 >= 20 || !FIRST) {
+      xx = x * x + xx; xy = x * y + xy; xz = x * z + xz; yy = y * y + yy; yz = y * z + yz; zz = z * z + zz;
+    } else {
+      xx = x * x; xy = x * y; xz = x * z; yy = y * y; yz = y * z; zz = z * z;
+    }
+  }
+
+  // One cell row with compile-time row residue RM = i & 3 (k & 7 depends on i only through i & 3 for even P).
+  // STATIC_I >= 0 marks rows whose index is known at compile time (needed for first/last/tail handling).
+  template <int RM, int STATIC_I>
+  __device__ __forceinline__ void row(const uint32_t (&w)[P / 2], const float (&cxj)[P], float cy_i, bool is_hrow,
+                                      const Params& prm, float rx, float ry) {
+    row_impl<RM, STATIC_I>(w, cxj, cy_i, is_hrow, prm, rx, ry, std::make_integer_sequence<int, P>{});
+  }
+  template <int RM, int STATIC_I, int... Js>
+  __device__ __forceinline__ void row_impl(const uint32_t (&w)[P / 2], const float (&cxj)[P], float cy_i, bool is_hrow,
+                                           const Params& prm, float rx, float ry, std::integer_sequence<int, Js...>) {
+    (one<RM, STATIC_I, Js>(w, cxj, cy_i, is_hrow, prm, rx, ry), ...);
+  }
+  template <int RM, int STATIC_I, int J>
+  __device__ __forceinline__ void one(const uint32_t (&w)[P / 2], const float (&cxj)[P], float cy_i, bool is_hrow,
+                                      const Params& prm, float rx, float ry) {
+    constexpr int KM = (RM * P + J) & 7;
+    constexpr int K = STATIC_I >= 0 ? STATIC_I * P + J : -1;
+    constexpr bool TAIL = K >= 0 && K >= A2;
+    constexpr int TAILIDX = TAIL ? K - A2 : 0;
+    constexpr bool FIRST = K == 0;
+    constexpr bool LAST = K == n - 1;
+    const uint32_t zi = (J & 1) ? (w[J >> 1] >> 16) : (w[J >> 1] & 0xFFFFu);
+    if (STATIC_I >= 0) {
+      pixel<J, KM, TAIL, TAILIDX, FIRST, LAST, STATIC_I == P / 2>(zi, cxj[J], cy_i, prm, rx, ry);
+    } else if (is_hrow) {
+      pixel<J, KM, false, 0, false, false, true>(zi, cxj[J], cy_i, prm, rx, ry);
+    } else {
+      pixel<J, KM, false, 0, false, false, false>(zi, cxj[J], cy_i, prm, rx, ry);
+    }
+    // Order barriers: the whole unrolled cell is one basic block, and without them instruction selection separates
+    // the work into phases (all converts/products first, the sequential chain adds last) and spills hundreds of
+    // values.  The empty asm pins every accumulator this pixel touched at this point of the instruction stream.
+    {
+      constexpr int CI = TAIL ? TAILIDX : KM;
+      asm volatile("" : "+v"(sx.c[CI]), "+v"(sy.c[CI]), "+v"(sz.c[CI]));
+    }
+    asm volatile("" : "+v"(xx), "+v"(xy), "+v"(xz), "+v"(yy), "+v"(yz), "+v"(zz));
+  }
+};
+
+template <int P>
+__device__ __forceinline__ void load_cell_row(const uint16_t* rowp, uint32_t (&w)[P / 2]) {
+  constexpr int DW = P / 2;
+  const uint32_t* rp = reinterpret_cast<const uint32_t*>(rowp);
+  int d = 0;
+#pragma unroll
+  for (; d + 4 <= DW; d += 4) {
+    const u32x4a v = *reinterpret_cast<const u32x4a*>(rp + d);
+    w[d] = v.x; w[d + 1] = v.y; w[d + 2] = v.z; w[d + 3] = v.w;
+  }
+  if (d + 2 <= DW) {
+    const u32x2a v = *reinterpret_cast<const u32x2a*>(rp + d);
+    w[d] = v.x; w[d + 1] = v.y;
+    d += 2;
+  }
+  if (d < DW) w[d] = rp[d];
+}
+
+template <int P, bool FASTDIV>
+__global__ __launch_bounds__(256, DPX_PF_WAVES) void k_planefit_depth(Params prm, const uint16_t* __restrict__ depth,
+                                                            dpx_cell* __restrict__ cells, float rx, float ry) {
+  static_assert(P % 2 == 0 && P >= 2, "even patch sizes only");
+  constexpr int n = P * P;
+  constexpr int DW = P / 2;  // dwords per cell row
+  constexpr int A2 = (n / 8) * 8;
+  // rows handled by the rolled 4-row loop: whole groups of rows that lie entirely inside the 8-wide part, never row 0
+  // (first-point bookkeeping) — row 0..3 are peeled as the static prologue group.
+  // rows [0, FULL) are whole 4-row groups below A2 that do not contain the last row (its last point is needed)
+  constexpr int FULL_A = ((A2 / P) / 4) * 4, FULL_B = ((P - 1) / 4) * 4;
+  constexpr int FULL = FULL_A < FULL_B ? FULL_A : FULL_B;
+  const int strips = (prm.nh + 63) >> 6;
+  const long long wave = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const long long per_frame = static_cast<long long>(prm.nv) * strips;
+  if (wave >= per_frame * prm.batch) return;
+  const int frame = static_cast<int>(wave / per_frame);
+  const int rem = static_cast<int>(wave - frame * per_frame);
+  const int cr = rem / strips;
+  const int cc = (rem - cr * strips) * 64 + lane;
+  if (cc >= prm.nh) return;
+
+  const int row0 = cr * P, col0 = cc * P;
+  const uint16_t* src = depth + static_cast<long long>(frame) * prm.N + static_cast<long long>(row0) * prm.W + col0;
+
+  float cxj[P];
+  bool all_neg_x = true, all_neg_y = true;
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    cxj[j] = static_cast<float>(col0 + j) - prm.cx;
+    all_neg_x = all_neg_x && (__builtin_signbit(cxj[j]) != __builtin_signbit(prm.fx));
+  }
+  for (int i = 0; i < P; ++i)
+    all_neg_y = all_neg_y && (__builtin_signbit(static_cast<float>(row0 + i) - prm.cy) != __builtin_signbit(prm.fy));
+
+  CellAcc<P, FASTDIV> acc;
+  acc.init();
+
+  // group buffers: `cur` holds the 4 rows being processed, `nxt` the 4 rows in flight behind them
+  uint32_t cur[4][DW], nxt[4][DW];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (r < P) load_cell_row<P>(src + static_cast<long long>(r) * prm.W, cur[r]);
+  {
+    const uint32_t wv = cur[0][(P / 2) / 2];
+    acc.vprev = static_cast<float>(((P / 2) & 1) ? (wv >> 16) : (wv & 0xFFFFu));  // k = P/2 -> (i = 0, j = P/2)
+  }
+
+  if (FULL >= 4) {
+    // ---- group 0 (rows 0..3), static row indices
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (4 + r < P) load_cell_row<P>(src + static_cast<long long>(4 + r) * prm.W, nxt[r]);
+    acc.template row<0, 0>(cur[0], cxj, static_cast<float>(row0 + 0) - prm.cy, false, prm, rx, ry);
+    acc.template row<1, 1>(cur[1], cxj, static_cast<float>(row0 + 1) - prm.cy, false, prm, rx, ry);
+    acc.template row<2, 2>(cur[2], cxj, static_cast<float>(row0 + 2) - prm.cy, false, prm, rx, ry);
+    acc.template row<3, 3>(cur[3], cxj, static_cast<float>(row0 + 3) - prm.cy, false, prm, rx, ry);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int d = 0; d < DW; ++d) cur[r][d] = nxt[r][d];
+    // ---- groups 1.. (rows 4..FULL-1), rolled: the row index is a runtime value, k & 7 is still static
+#pragma nounroll
+    for (int g = 4; g < FULL; g += 4) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (g + 4 + r < P) load_cell_row<P>(src + static_cast<long long>(g + 4 + r) * prm.W, nxt[r]);
+      acc.template row<0, -1>(cur[0], cxj, static_cast<float>(row0 + g + 0) - prm.cy, g + 0 == P / 2, prm, rx, ry);
+      acc.template row<1, -1>(cur[1], cxj, static_cast<float>(row0 + g + 1) - prm.cy, g + 1 == P / 2, prm, rx, ry);
+      acc.template row<2, -1>(cur[2], cxj, static_cast<float>(row0 + g + 2) - prm.cy, g + 2 == P / 2, prm, rx, ry);
+      acc.template row<3, -1>(cur[3], cxj, static_cast<float>(row0 + g + 3) - prm.cy, g + 3 == P / 2, prm, rx, ry);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int d = 0; d < DW; ++d) cur[r][d] = nxt[r][d];
+    }
+  }
+  // ---- remaining rows FULL..P-1 (at most 3 + the rows that contain the trailing packet), static indices
+  {
+    constexpr int R0 = FULL >= 4 ? FULL : 0;
+    if (R0 + 0 < P) acc.template row<(R0 + 0) & 3, R0 + 0 < P ? R0 + 0 : 0>(cur[0], cxj, static_cast<float>(row0 + R0 + 0) - prm.cy, false, prm, rx, ry);
+    if (R0 + 1 < P) acc.template row<(R0 + 1) & 3, R0 + 1 < P ? R0 + 1 : 0>(cur[1], cxj, static_cast<float>(row0 + R0 + 1) - prm.cy, false, prm, rx, ry);
+    if (R0 + 2 < P) acc.template row<(R0 + 2) & 3, R0 + 2 < P ? R0 + 2 : 0>(cur[2], cxj, static_cast<float>(row0 + R0 + 2) - prm.cy, false, prm, rx, ry);
+    if (R0 + 3 < P) acc.template row<(R0 + 3) & 3, R0 + 3 < P ? R0 + 3 : 0>(cur[3], cxj, static_cast<float>(row0 + R0 + 3) - prm.cy, false, prm, rx, ry);
+    static_assert(P - R0 <= 4, "at most one partial group after the rolled loop");
+  }
+
+  if (A2 > 0 && n == A2) { acc.sx.fold(); acc.sy.fold(); acc.sz.fold(); }
+  float sum[3], pp[6];
+  sum[0] = (acc.sx.c[0] + acc.sx.c[2]) + (acc.sx.c[1] + acc.sx.c[3]);
+  sum[1] = (acc.sy.c[0] + acc.sy.c[2]) + (acc.sy.c[1] + acc.sy.c[3]);
+  sum[2] = (acc.sz.c[0] + acc.sz.c[2]) + (acc.sz.c[1] + acc.sz.c[3]);
+  if (FASTDIV && acc.valid_pts == 0) {  // every x and y is a signed zero: restore the IEEE sign of the sums
+    sum[0] = all_neg_x ? -0.0f : 0.0f;
+    sum[1] = all_neg_y ? -0.0f : 0.0f;
+  }
+  pp[0] = acc.xx; pp[1] = acc.xy; pp[2] = acc.xz; pp[3] = acc.yy; pp[4] = acc.yz; pp[5] = acc.zz;
+  const bool cont = (acc.hdisc < prm.max_disc) && (acc.vdisc < prm.max_disc);
+  const bool valid = prm.valid_thr >= 0 && static_cast<long long>(acc.valid_pts) >= prm.valid_thr && cont;
+
+  dpx_cell rec;
+  finish_cell(prm, n, sum, pp, acc.fx0 - acc.lx, acc.fy0 - acc.ly, acc.fz0 - acc.lz, valid, rec);
+  float4* dst = reinterpret_cast<float4*>(cells + static_cast<long long>(frame) * prm.C + static_cast<long long>(cr) * prm.nh + cc);
+  const float4* s4 = reinterpret_cast<const float4*>(&rec);
+  dst[0] = s4[0];
+  dst[1] = s4[1];
+  dst[2] = s4[2];
+  dst[3] = s4[3];
+}
+
+}  // namespace dpx

@@ -132,6 +132,12 @@ class PlaneExtractor:
     def process_pcd_device(self, d_xyz_ptr: int, batch: int, d_labels_ptr: int, stream: int = 0):
         _capi.check(_capi.lib().dpx_process_pcd_batch_device(self._h, d_xyz_ptr, batch, d_labels_ptr, stream))
 
+    def prepare_intrinsics(self, fx, fy, cx, cy) -> bool:
+        """Runs the one-time exact-division check for these intrinsics; True if the fast sequence is exact."""
+        ok = C.c_int32()
+        _capi.check(_capi.lib().dpx_prepare_intrinsics(self._h, fx, fy, cx, cy, C.byref(ok)))
+        return bool(ok.value)
+
     # ---- records of the last call -----------------------------------------------------------------------
     def cells(self, frame: int = 0) -> np.ndarray:
         out = np.zeros(self.nh * self.nv, dtype=_capi.CELL_DTYPE)

@@ -131,6 +131,12 @@ int dpx_process_depth_batch_device(dpx_handle h, const void* d_depth, int32_t ba
                                    float cy, void* d_labels, void* hip_stream);
 int dpx_process_pcd_batch_device(dpx_handle h, const void* d_xyz, int32_t batch, void* d_labels, void* hip_stream);
 
+/* Optional: validate intrinsics ahead of the first depth call (the fused kernel divides by fx, fy through a
+ * reciprocal sequence that is checked exhaustively against IEEE division for this image geometry; the check
+ * synchronises once per new intrinsics tuple, so call this before capturing a HIP graph).  *fast_division
+ * receives 1 if the fast sequence is exact for these intrinsics, 0 if the kernel will use IEEE division. */
+int dpx_prepare_intrinsics(dpx_handle h, float fx, float fy, float cx, float cy, int32_t* fast_division);
+
 /* DepthImage::toPointCloud — utils/depth_image.cpp:55-78: depth H x W uint16 (HOST) -> xyz N x 3 float32 (HOST). */
 int dpx_backproject(const uint16_t* depth, int32_t height, int32_t width, float fx, float fy, float cx, float cy,
                     float* xyz, int32_t device);
