@@ -12,7 +12,8 @@ from pathlib import Path
 import numpy as np
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "lib" / "libdeplex_amd.so"
+# DPX_LIB_PATH selects another build of the same library (kernel tuning experiments); default is the in-tree build
+LIB_PATH = Path(os.environ["DPX_LIB_PATH"]) if os.environ.get("DPX_LIB_PATH") else _PKG / "lib" / "libdeplex_amd.so"
 
 DPX_OK = 0
 DPX_ERR_PATCH_ZERO = -1
@@ -77,6 +78,7 @@ SYMBOLS = {
     "dpx_get_cell_labels": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "dpx_get_planes": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]),
     "dpx_get_frame_stats": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "dpx_debug_region_phases": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dpx_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "dpx_get_kernel_ms": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dpx_time_planefit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.POINTER(C.c_float)]),

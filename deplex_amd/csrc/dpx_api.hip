@@ -15,6 +15,7 @@
 #include "dpx_kernels.h"
 #include "dpx_planefit_fast.h"
 #include "dpx_regions.h"
+#include "dpx_regions2.h"
 
 namespace {
 
@@ -57,6 +58,11 @@ struct dpx_handle_s {
   uint2* d_pairs = nullptr;
   int32_t* d_merge = nullptr;
   dpx_frame_stats* d_stats = nullptr;
+  unsigned long long* d_dbg = nullptr;  // diagnostic phase stamps (dpx_debug_region_phases)
+  float* d_mse_c = nullptr;
+  uint32_t* d_cand_grow = nullptr;
+  int regions_tier = 0;  // 2 = k_regions2<FULL>, 1 = k_regions2<LEAN>, 0 = k_regions (v1)
+  size_t lds2_bytes = 0;
   uint8_t* d_gflags = nullptr;
   uint8_t* d_gowner = nullptr;
   uint32_t* d_gqueue = nullptr;
@@ -99,6 +105,9 @@ void free_all(dpx_handle h) {
   hipFree(h->d_pairs);
   hipFree(h->d_merge);
   hipFree(h->d_stats);
+  hipFree(h->d_dbg);
+  hipFree(h->d_mse_c);
+  hipFree(h->d_cand_grow);
   hipFree(h->d_gflags);
   hipFree(h->d_gowner);
   hipFree(h->d_gqueue);
@@ -143,7 +152,12 @@ template <int P>
 void launch_planefit_fast(const dpx::Params& prm, const void* d_in, dpx_cell* d_cells, hipStream_t s, bool fastdiv, float rx, float ry) {
   const long long waves = static_cast<long long>(prm.batch) * prm.nv * ((prm.nh + 63) / 64);
   const unsigned blocks = static_cast<unsigned>((waves + 3) / 4);
-  if (fastdiv)
+  static const int diag = std::getenv("DPX_PF_DIAG") ? std::atoi(std::getenv("DPX_PF_DIAG")) : 0;
+  if (P == 10 && diag == 1)
+    hipLaunchKernelGGL((dpx::k_planefit_depth<10, true, 1>), dim3(blocks), dim3(256), 0, s, prm, static_cast<const uint16_t*>(d_in), d_cells, rx, ry);
+  else if (P == 10 && diag == 2)
+    hipLaunchKernelGGL((dpx::k_planefit_depth<10, true, 2>), dim3(blocks), dim3(256), 0, s, prm, static_cast<const uint16_t*>(d_in), d_cells, rx, ry);
+  else if (fastdiv)
     hipLaunchKernelGGL((dpx::k_planefit_depth<P, true>), dim3(blocks), dim3(256), 0, s, prm, static_cast<const uint16_t*>(d_in), d_cells, rx, ry);
   else
     hipLaunchKernelGGL((dpx::k_planefit_depth<P, false>), dim3(blocks), dim3(256), 0, s, prm, static_cast<const uint16_t*>(d_in), d_cells, rx, ry);
@@ -205,14 +219,21 @@ int run_pipeline(dpx_handle h, const void* d_in, bool depth, int batch, float fx
   if (prof) DPX_HIP(hipEventRecord(ev[1], s));
   const long long total = static_cast<long long>(batch) * prm.C;
   if (total > 0)
-    hipLaunchKernelGGL(dpx::k_cellgraph, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, prm, h->d_cells, h->d_meta);
+    hipLaunchKernelGGL(dpx::k_cellgraph, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, prm, h->d_cells, h->d_meta, h->d_mse_c);
   if (prof) DPX_HIP(hipEventRecord(ev[2], s));
   dpx::RegionBufs rb{};
   rb.cells = h->d_cells; rb.meta = h->d_meta; rb.order = h->d_order; rb.grow_start = h->d_grow_start;
   rb.cand = h->d_cand; rb.planes = h->d_planes; rb.cell_labels = h->d_cell_labels; rb.pairs = h->d_pairs;
   rb.merge = h->d_merge; rb.stats = h->d_stats; rb.g_flags = h->d_gflags; rb.g_owner = h->d_gowner;
   rb.g_queue = h->d_gqueue; rb.pcap = h->pcap;
-  if (h->use_lds)
+  dpx::Regions2Extra rx{h->d_mse_c, h->d_cand_grow, h->d_dbg};
+  if (h->regions_tier == 2 && h->d_dbg)
+    hipLaunchKernelGGL((dpx::k_regions2<true, true>), dim3(batch), dim3(256), h->lds2_bytes, s, prm, rb, rx);
+  else if (h->regions_tier == 2)
+    hipLaunchKernelGGL((dpx::k_regions2<true, false>), dim3(batch), dim3(256), h->lds2_bytes, s, prm, rb, rx);
+  else if (h->regions_tier == 1)
+    hipLaunchKernelGGL((dpx::k_regions2<false, false>), dim3(batch), dim3(256), h->lds2_bytes, s, prm, rb, rx);
+  else if (h->use_lds)
     hipLaunchKernelGGL(dpx::k_regions<true>, dim3(batch), dim3(64), h->lds_bytes, s, prm, rb);
   else
     hipLaunchKernelGGL(dpx::k_regions<false>, dim3(batch), dim3(64), h->lds_bytes, s, prm, rb);
@@ -436,6 +457,22 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
   h->pcap = static_cast<int>(std::max<long long>(1, cfg->min_region_growing_cells_activated <= 1
                                                       ? static_cast<long long>(C)
                                                       : static_cast<long long>(C) / cfg->min_region_growing_cells_activated));
+  {
+    // region-growing kernel tier: everything in LDS (13 B/cell), lean (7 B/cell), or the v1 kernel
+    const size_t fixed = 64 + hist_bytes + 4 * 64 * 9 * 4 + 64;
+    const char* v1 = std::getenv("DPX_REGIONS_V1");
+    const char* lean = std::getenv("DPX_REGIONS_LEAN");
+    h->regions_tier = 0;
+    if (!(v1 && v1[0] == '1') && !(force && force[0] == '1') && C < 65000 && nb < 4600) {
+      if (fixed + 13 * C <= kLdsLimit && !(lean && lean[0] == '1')) {
+        h->regions_tier = 2;
+        h->lds2_bytes = fixed + 13 * C;
+      } else if (fixed + 7 * C <= kLdsLimit) {
+        h->regions_tier = 1;
+        h->lds2_bytes = fixed + 7 * C;
+      }
+    }
+  }
   const size_t B = static_cast<size_t>(max_batch);
   int rc = DPX_OK;
   auto A = [&](int r) { if (rc == DPX_OK) rc = r; };
@@ -449,6 +486,8 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
   A(dev_alloc(&h->d_pairs, B * 2 * C));
   A(dev_alloc(&h->d_merge, B * h->pcap));
   A(dev_alloc(&h->d_stats, B));
+  A(dev_alloc(&h->d_mse_c, B * C));
+  A(dev_alloc(&h->d_cand_grow, B * h->pcap));
   if (!h->use_lds) {
     A(dev_alloc(&h->d_gflags, B * C));
     A(dev_alloc(&h->d_gowner, B * C));
@@ -462,6 +501,13 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
                                : hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions<false>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds_bytes));
     if (e2 != hipSuccess) rc = fail(DPX_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e2));
+  }
+  if (rc == DPX_OK && h->regions_tier > 0 && h->lds2_bytes > 48 * 1024) {
+    hipError_t e3 = h->regions_tier == 2 ? hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<true, false>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds2_bytes))
+                                         : hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<false, false>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds2_bytes));
+    if (e3 != hipSuccess) rc = fail(DPX_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e3));
   }
   if (rc != DPX_OK) {
     const std::string keep = g_err;
@@ -569,7 +615,7 @@ int dpx_get_cell_edges(dpx_handle h, int32_t frame, uint8_t* out) {
   const size_t C = h->prm.C;
   std::vector<uint32_t> tmp(C);
   if (C) DPX_HIP(hipMemcpy(tmp.data(), h->d_meta + frame * C, C * 4, hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < C; ++i) out[i] = static_cast<uint8_t>(tmp[i] & 0xFF);
+  for (size_t i = 0; i < C; ++i) out[i] = static_cast<uint8_t>(tmp[i] & 0x3F);
   return DPX_OK;
 }
 
@@ -604,6 +650,27 @@ int dpx_prepare_intrinsics(dpx_handle h, float fx, float fy, float cx, float cy,
   const int rc = prepare_intrinsics(h, fx, fy, cx, cy);
   if (rc == DPX_OK && fast_division) *fast_division = h->fd_ok ? 1 : 0;
   return rc;
+}
+
+int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_t* out16) {
+  if (!h) return fail(DPX_ERR_ARG, "null handle");
+  DPX_HIP(hipSetDevice(h->device));
+  if (enable && !h->d_dbg) {
+    DPX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_dbg), static_cast<size_t>(h->max_batch) * 16 * sizeof(unsigned long long)));
+    DPX_HIP(hipMemset(h->d_dbg, 0, static_cast<size_t>(h->max_batch) * 16 * sizeof(unsigned long long)));
+    if (h->lds2_bytes > 48 * 1024)
+      DPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds2_bytes)));
+  }
+  if (out16) {
+    if (!h->d_dbg || frame < 0 || frame >= h->max_batch) return fail(DPX_ERR_ARG, "diagnostics not enabled or bad frame");
+    DPX_HIP(hipStreamSynchronize(h->last_stream));
+    DPX_HIP(hipMemcpy(out16, h->d_dbg + static_cast<size_t>(frame) * 16, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  }
+  if (!enable && h->d_dbg) {
+    hipFree(h->d_dbg);
+    h->d_dbg = nullptr;
+  }
+  return DPX_OK;
 }
 
 int dpx_set_profiling(dpx_handle h, int32_t enable) {

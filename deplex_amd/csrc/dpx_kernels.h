@@ -35,6 +35,8 @@ constexpr uint32_t CELL_VALID = 1u, CELL_PLANAR = 2u, CELL_QL = 4u;
 // cell meta byte (k_cellgraph output / region-growing flags)
 constexpr uint32_t F_UNASSIGNED = 1u;          // planar and not yet grown
 constexpr uint32_t F_EDGE0 = 4u;               // bits 2..5: edge to U, D, L, R neighbour passes the predicate
+constexpr uint32_t F_INEDGE0 = 256u;           // bits 8..11: edge FROM the U, D, L, R neighbour to this cell passes it
+constexpr int META_BIN_SHIFT = 12;             // bits 12..31: histogram bin + 1 (0 = none)
 
 // ------------------------------------------------------------------------------------------------------
 // Point access.  Cloud index q of cell point (i, j) is (cr*P+i)*stride_w + cc*P + j (cell_grid.cpp:74-80),
@@ -352,8 +354,10 @@ __global__ __launch_bounds__(256) void k_planefit(Params prm, const void* __rest
 // K3: directed edge bits.  Edge u->v is set iff both cells are planar and growSeed would accept v from u
 // ignoring the dynamic unassigned/activated state (plane_extractor.cpp:377-383):
 //   n_u . n_v >= min_cos  &&  (n_u . mean_v + d_u)^2 <= tol_v        (comparisons in double)
-// Output: one uint32 per cell: bits 0..7 flags (F_UNASSIGNED, F_EDGE0<<dir), bits 8..31 histogram bin + 1.
-__global__ __launch_bounds__(256) void k_cellgraph(Params prm, const dpx_cell* __restrict__ cells, uint32_t* __restrict__ meta) {
+// Output: one uint32 per cell: bit 0 planar, bits 2..5 out-edges, bits 8..11 in-edges, bits 12..31 histogram bin + 1,
+// plus the cell mse as a compact float array.
+__global__ __launch_bounds__(256) void k_cellgraph(Params prm, const dpx_cell* __restrict__ cells, uint32_t* __restrict__ meta,
+                                                   float* __restrict__ mse_c) {
   const long long gid = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
   const long long total = static_cast<long long>(prm.batch) * prm.C;
   if (gid >= total) return;
@@ -364,10 +368,12 @@ __global__ __launch_bounds__(256) void k_cellgraph(Params prm, const dpx_cell* _
   const uint32_t info = fc[c].info;
   uint32_t m = 0;
   if (info & CELL_PLANAR) {
-    m = F_UNASSIGNED | (info & 0xFFFFFF00u);
+    m = F_UNASSIGNED | ((info >> 8) << META_BIN_SHIFT);
     const float nx = fc[c].normal[0], ny = fc[c].normal[1], nz = fc[c].normal[2];
     const double du = static_cast<double>(fc[c].d);
     const float nf = static_cast<float>(prm.n);
+    const float smx = fc[c].sum[0] / nf, smy = fc[c].sum[1] / nf, smz = fc[c].sum[2] / nf;  // own mean (for in-edges)
+    const double tol_self = static_cast<double>(fc[c].tol);
     const int nb[4] = {cr >= 1 ? c - prm.nh : -1, cr + 1 < prm.nv ? c + prm.nh : -1, cc >= 1 ? c - 1 : -1,
                        cc + 1 < prm.nh ? c + 1 : -1};
 #pragma unroll
@@ -377,14 +383,18 @@ __global__ __launch_bounds__(256) void k_cellgraph(Params prm, const dpx_cell* _
       const dpx_cell& cv = fc[v];
       if (!(cv.info & CELL_PLANAR)) continue;
       const float cosf_ = dot3(nx, ny, nz, cv.normal[0], cv.normal[1], cv.normal[2]);
+      if (!(static_cast<double>(cosf_) >= static_cast<double>(prm.min_cos))) continue;  // the cosine is symmetric
+      // out-edge  c -> v : (n_c . mean_v + d_c)^2 <= tol_v
       const float mx = cv.sum[0] / nf, my = cv.sum[1] / nf, mzv = cv.sum[2] / nf;  // mean_ = coord_sum_/nr_pts_
       const double tt = static_cast<double>(dot3(nx, ny, nz, mx, my, mzv)) + du;
-      const double dist = tt * tt;
-      if (static_cast<double>(cosf_) >= static_cast<double>(prm.min_cos) && dist <= static_cast<double>(cv.tol))
-        m |= (F_EDGE0 << dir);
+      if (tt * tt <= static_cast<double>(cv.tol)) m |= (F_EDGE0 << dir);
+      // in-edge   v -> c : (n_v . mean_c + d_v)^2 <= tol_c
+      const double ti = static_cast<double>(dot3(cv.normal[0], cv.normal[1], cv.normal[2], smx, smy, smz)) + static_cast<double>(cv.d);
+      if (ti * ti <= tol_self) m |= (F_INEDGE0 << dir);
     }
   }
   meta[gid] = m;
+  mse_c[gid] = fc[c].mse;  // compact copy for the region-growing kernel's seed search
 }
 
 // ------------------------------------------------------------------------------------------------------

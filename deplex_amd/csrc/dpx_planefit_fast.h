@@ -27,6 +27,9 @@
 
 namespace dpx {
 
+#ifndef DPX_PF_GROUP
+#define DPX_PF_GROUP 2
+#endif
 #ifndef DPX_PF_WAVES
 #define DPX_PF_WAVES 4
 #endif
@@ -160,12 +163,14 @@ struct CellAcc {
     }
     // Order barriers: the whole unrolled cell is one basic block, and without them instruction selection separates
     // the work into phases (all converts/products first, the sequential chain adds last) and spills hundreds of
-    // values.  The empty asm pins every accumulator this pixel touched at this point of the instruction stream.
-    {
-      constexpr int CI = TAIL ? TAILIDX : KM;
-      asm volatile("" : "+v"(sx.c[CI]), "+v"(sy.c[CI]), "+v"(sz.c[CI]));
+    // values.  The empty asm pins every accumulator touched by the last DPX_PF_GROUP pixels at this point of the
+    // instruction stream; inside a group the scheduler is free to interleave the pixels' independent work (ILP).
+    if ((J % DPX_PF_GROUP) == DPX_PF_GROUP - 1 || J == P - 1) {
+      asm volatile("" : "+v"(sx.c[0]), "+v"(sx.c[1]), "+v"(sx.c[2]), "+v"(sx.c[3]), "+v"(sx.c[4]), "+v"(sx.c[5]), "+v"(sx.c[6]), "+v"(sx.c[7]));
+      asm volatile("" : "+v"(sy.c[0]), "+v"(sy.c[1]), "+v"(sy.c[2]), "+v"(sy.c[3]), "+v"(sy.c[4]), "+v"(sy.c[5]), "+v"(sy.c[6]), "+v"(sy.c[7]));
+      asm volatile("" : "+v"(sz.c[0]), "+v"(sz.c[1]), "+v"(sz.c[2]), "+v"(sz.c[3]), "+v"(sz.c[4]), "+v"(sz.c[5]), "+v"(sz.c[6]), "+v"(sz.c[7]));
+      asm volatile("" : "+v"(xx), "+v"(xy), "+v"(xz), "+v"(yy), "+v"(yz), "+v"(zz));
     }
-    asm volatile("" : "+v"(xx), "+v"(xy), "+v"(xz), "+v"(yy), "+v"(yz), "+v"(zz));
   }
 };
 
@@ -187,7 +192,9 @@ __device__ __forceinline__ void load_cell_row(const uint16_t* rowp, uint32_t (&w
   if (d < DW) w[d] = rp[d];
 }
 
-template <int P, bool FASTDIV>
+// DIAG != 0 are timing-only instantiations (results are garbage): 1 = skip the plane fit / record maths (moments only),
+// 2 = loads + record store only.  Selected with DPX_PF_DIAG for tools/pf_breakdown.py; never used by the product path.
+template <int P, bool FASTDIV, int DIAG = 0>
 __global__ __launch_bounds__(256, DPX_PF_WAVES) void k_planefit_depth(Params prm, const uint16_t* __restrict__ depth,
                                                             dpx_cell* __restrict__ cells, float rx, float ry) {
   static_assert(P % 2 == 0 && P >= 2, "even patch sizes only");
@@ -236,7 +243,24 @@ __global__ __launch_bounds__(256, DPX_PF_WAVES) void k_planefit_depth(Params prm
     acc.vprev = static_cast<float>(((P / 2) & 1) ? (wv >> 16) : (wv & 0xFFFFu));  // k = P/2 -> (i = 0, j = P/2)
   }
 
-  if (FULL >= 4) {
+  if (DIAG == 2) {
+    // loads + store only: fold the raw words so that the loads stay live
+    uint32_t x = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int d = 0; d < DW; ++d) x ^= cur[r][d];
+    for (int g = 4; g < P; g += 4) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (g + r < P) {
+          load_cell_row<P>(src + static_cast<long long>(g + r) * prm.W, nxt[r]);
+#pragma unroll
+          for (int d = 0; d < DW; ++d) x ^= nxt[r][d];
+        }
+    }
+    acc.xx = __uint_as_float(x);
+  } else if (FULL >= 4) {
     // ---- group 0 (rows 0..3), static row indices
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -266,7 +290,7 @@ __global__ __launch_bounds__(256, DPX_PF_WAVES) void k_planefit_depth(Params prm
     }
   }
   // ---- remaining rows FULL..P-1 (at most 3 + the rows that contain the trailing packet), static indices
-  {
+  if (DIAG != 2) {
     constexpr int R0 = FULL >= 4 ? FULL : 0;
     if (R0 + 0 < P) acc.template row<(R0 + 0) & 3, R0 + 0 < P ? R0 + 0 : 0>(cur[0], cxj, static_cast<float>(row0 + R0 + 0) - prm.cy, false, prm, rx, ry);
     if (R0 + 1 < P) acc.template row<(R0 + 1) & 3, R0 + 1 < P ? R0 + 1 : 0>(cur[1], cxj, static_cast<float>(row0 + R0 + 1) - prm.cy, false, prm, rx, ry);
@@ -289,7 +313,24 @@ __global__ __launch_bounds__(256, DPX_PF_WAVES) void k_planefit_depth(Params prm
   const bool valid = prm.valid_thr >= 0 && static_cast<long long>(acc.valid_pts) >= prm.valid_thr && cont;
 
   dpx_cell rec;
-  finish_cell(prm, n, sum, pp, acc.fx0 - acc.lx, acc.fy0 - acc.ly, acc.fz0 - acc.lz, valid, rec);
+  if (DIAG == 0) {
+    if (valid) {
+      finish_cell(prm, n, sum, pp, acc.fx0 - acc.lx, acc.fy0 - acc.ly, acc.fz0 - acc.lz, true, rec);
+    } else {  // the reference does not compute statistics for invalid cells either (cell_segment.cpp:30)
+      rec.sum[0] = rec.sum[1] = rec.sum[2] = 0.f;
+      rec.pp[0] = rec.pp[1] = rec.pp[2] = rec.pp[3] = rec.pp[4] = rec.pp[5] = 0.f;
+      rec.normal[0] = rec.normal[1] = rec.normal[2] = 0.f;
+      rec.d = 0.f;
+      rec.mse = 3.402823466e+38f;
+      rec.tol = 0.f;
+      rec.info = 0u;
+    }
+  } else {
+    rec.sum[0] = sum[0]; rec.sum[1] = sum[1]; rec.sum[2] = sum[2];
+    rec.pp[0] = pp[0]; rec.pp[1] = pp[1]; rec.pp[2] = pp[2]; rec.pp[3] = pp[3]; rec.pp[4] = pp[4]; rec.pp[5] = pp[5];
+    rec.normal[0] = acc.fx0 - acc.lx; rec.normal[1] = acc.fy0 - acc.ly; rec.normal[2] = acc.fz0 - acc.lz;
+    rec.d = 0.f; rec.mse = 0.f; rec.tol = 0.f; rec.info = valid ? 1u : 0u;
+  }
   float4* dst = reinterpret_cast<float4*>(cells + static_cast<long long>(frame) * prm.C + static_cast<long long>(cr) * prm.nh + cc);
   const float4* s4 = reinterpret_cast<const float4*>(&rec);
   dst[0] = s4[0];

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64) void k_regions(Params prm, RegionBufs rb) {
     cell_labels[c] = 0;
     if (m & F_UNASSIGNED) {
       ++planar_cnt;
-      const int b = static_cast<int>(m >> 8) - 1;
+      const int b = static_cast<int>(m >> META_BIN_SHIFT) - 1;
       if (b >= 0 && b < nb) atomicAdd(&hist[b], 1);
     }
   }
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64) void k_regions(Params prm, RegionBufs rb) {
   for (int c = lane; c < C; c += 64) {
     const uint32_t m = meta[c];
     if (m & F_UNASSIGNED) {
-      const int b = static_cast<int>(m >> 8) - 1;
+      const int b = static_cast<int>(m >> META_BIN_SHIFT) - 1;
       if (b >= 0 && b < nb) {
         const int pos = atomicAdd(&cursor[b], 1);
         order[pos] = static_cast<uint32_t>(c);
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(64) void k_regions(Params prm, RegionBufs rb) {
     const int g = tail - gstart;
     // hist.removePoint for every grown cell (:324)
     for (int i = gstart + lane; i < tail; i += 64) {
-      const int b = static_cast<int>(meta[queue[i]] >> 8) - 1;
+      const int b = static_cast<int>(meta[queue[i]] >> META_BIN_SHIFT) - 1;
       if (b >= 0 && b < nb) atomicSub(&hist[b], 1);
     }
     if (lane == 0) grow_start[ngrow] = static_cast<uint32_t>(gstart);

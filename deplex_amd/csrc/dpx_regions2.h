@@ -1,0 +1,555 @@
+// dpx_regions2.h — K4+K5, second generation: one 256-thread workgroup per frame.
+//
+// Same algorithm and the same bit-exact results as dpx_regions.h (kept as the fallback for frames whose state does
+// not fit LDS); what changes is where the time goes:
+//   * all per-cell state of the sequential phase lives in LDS (flags, queue, queue position, bin-sorted order, and in
+//     the FULL tier also the cell's bin and mse), so a seed iteration never waits on HBM/L2;
+//   * the LDS flag byte of a cell holds its IN-edges (which neighbours may activate it, k_cellgraph bits 8..11), so a
+//     BFS lane needs only the target cell's byte, and duplicate resolution is PULL based: the lane reads the queue
+//     positions of the target's four neighbours and loses to any in-neighbour that sits earlier in the current FIFO
+//     batch — 2 dependent LDS round trips per BFS step instead of ~8 for the claim/re-claim protocol of v1;
+//   * a grown cell leaves the histogram at activation time (LDS atomic), the arg-max runs over a register-resident
+//     list of the non-empty bins, and the seed search compacts the bin's cell list in place as it scans it;
+//   * wave reductions use DPP row shifts/broadcasts (gfx9) instead of ds_bpermute butterflies;
+//   * the parallel phases (state load, float accumulation of the grown segments, f64 segment fits, label writes) use
+//     all four waves; the inherently sequential seed loop runs on wave 0 while the others wait at the barrier.
+// Reference: plane_extractor.cpp:297-453, normals_histogram.cpp:51-72 (see dpx_regions.h for the parity notes).
+#pragma once
+#include "dpx_regions.h"
+
+namespace dpx {
+
+
+// DPP controls (gfx9): row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143
+#define DPX_DPP(x, ctrl, rmask, bmask) \
+  static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(x), static_cast<int>(x), ctrl, rmask, bmask, false))
+
+// max over the 64 lanes, returned in every lane (via readlane 63)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
+  uint32_t t;
+  t = DPX_DPP(x, 0x111, 0xf, 0xf); x = x > t ? x : t;
+  t = DPX_DPP(x, 0x112, 0xf, 0xf); x = x > t ? x : t;
+  t = DPX_DPP(x, 0x114, 0xf, 0xf); x = x > t ? x : t;
+  t = DPX_DPP(x, 0x118, 0xf, 0xf); x = x > t ? x : t;
+  t = DPX_DPP(x, 0x142, 0xa, 0xf); x = x > t ? x : t;
+  t = DPX_DPP(x, 0x143, 0xc, 0xf); x = x > t ? x : t;
+  return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(x), 63));
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) { return ~wave_max_u32(~x); }
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// float -> uint32 preserving < order (zeros canonicalised to +0 by the caller)
+__device__ __forceinline__ uint32_t ordered_f32(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+struct Regions2Extra {
+  const float* mse_c;   // [B][C] compact per-cell mse (k_cellgraph output)
+  uint32_t* cand_grow;  // [B][pcap] grow index of each candidate segment
+  unsigned long long* dbg;  // diagnostic build only: [B][16] shader-clock stamps / sums
+};
+
+#define DPX_STAMP() (DBG ? static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) : 0ull)
+
+// DBG = true is a separate diagnostic instantiation (phase timing through s_memtime); production uses DBG = false.
+template <bool FULL, bool DBG>
+__global__ __launch_bounds__(256) void k_regions2(Params prm, RegionBufs rb, Regions2Extra rx) {
+  unsigned long long t_start = DPX_STAMP(), t_p0 = 0, t_p1 = 0, t_p2 = 0, t_p3 = 0, t_p4 = 0, t_p5 = 0;
+  unsigned long long a_argmax = 0, a_seed = 0, a_bfs = 0, a_rem = 0, n_steps = 0;
+  const int frame = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int C = prm.C, nh = prm.nh, nv = prm.nv;
+  const int nb = prm.hist_B * prm.hist_B;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+  extern __shared__ __align__(16) unsigned char smem[];
+  int* hdr = reinterpret_cast<int*>(smem);  // 16 ints: 0 planar count, 1 tail, 2 ngrow, 3 ncand, 4 nplanes, 8..11 wave counts
+  int* hist = hdr + 16;
+  int* bin_start = hist + nb;        // nb + 1
+  int* cursor = bin_start + nb + 1;  // nb
+  float* stage = reinterpret_cast<float*>(cursor + nb);  // 4 waves x 64 entries x 9 floats
+  float* mse_l = stage + 4 * 64 * 9;                     // FULL: C floats
+  uint16_t* qpos = reinterpret_cast<uint16_t*>(mse_l + (FULL ? C : 0));
+  uint16_t* queue = qpos + C;
+  uint16_t* order = queue + C;
+  uint16_t* binof = order + C;  // FULL: C (bin + 1)
+  uint8_t* flags = reinterpret_cast<uint8_t*>(binof + (FULL ? C : 0));
+  // (the list of non-empty bins lives in the first nb uint16 of `stage` during P1; stage is not used before P2)
+  uint16_t* nzlist = reinterpret_cast<uint16_t*>(stage);
+
+  const dpx_cell* cells = rb.cells + static_cast<size_t>(frame) * C;
+  const uint32_t* meta = rb.meta + static_cast<size_t>(frame) * C;
+  const float* mse_c = rx.mse_c + static_cast<size_t>(frame) * C;
+  uint32_t* grow_start = rb.grow_start + static_cast<size_t>(frame) * (C + 1);
+  uint32_t* cand_grow = rx.cand_grow + static_cast<size_t>(frame) * rb.pcap;
+  float* cand = rb.cand + static_cast<size_t>(frame) * rb.pcap * 12;
+  dpx_plane* planes = rb.planes + static_cast<size_t>(frame) * rb.pcap;
+  int32_t* cell_labels = rb.cell_labels + static_cast<size_t>(frame) * C;
+  uint2* pairs = rb.pairs + static_cast<size_t>(frame) * 2 * C;
+  int32_t* merge = rb.merge + static_cast<size_t>(frame) * rb.pcap;
+
+  // ---------------- P0: state into LDS, histogram, bin-grouped order ------------------------------------
+  for (int b = tid; b < nb; b += 256) hist[b] = 0;
+  if (tid < 16) hdr[tid] = 0;
+  __syncthreads();
+  {
+    int planar_cnt = 0;
+    for (int c = tid; c < C; c += 256) {
+      const uint32_t m = meta[c];
+      // LDS flag byte: bit 0 unassigned, bits 2..5 IN-edges (neighbour U/D/L/R of this cell may activate it)
+      flags[c] = static_cast<uint8_t>((m & F_UNASSIGNED) | (((m >> 8) & 0xFu) << 2));
+      qpos[c] = 0xFFFFu;
+      cell_labels[c] = 0;
+      if (FULL) {
+        binof[c] = static_cast<uint16_t>(m >> META_BIN_SHIFT);
+        mse_l[c] = mse_c[c];
+      }
+      if (m & F_UNASSIGNED) {
+        ++planar_cnt;
+        const int b = static_cast<int>(m >> META_BIN_SHIFT) - 1;
+        if (b >= 0 && b < nb) atomicAdd(&hist[b], 1);
+      }
+    }
+    planar_cnt = wave_sum(planar_cnt);
+    if (lane == 0) atomicAdd(&hdr[0], planar_cnt);
+  }
+  __syncthreads();
+  if (wid == 0) {
+    int carry = 0;
+    for (int base = 0; base < nb; base += 64) {
+      const int b = base + lane;
+      const int v = b < nb ? hist[b] : 0;
+      const int incl = wave_incl_scan(v, lane);
+      if (b < nb) {
+        bin_start[b] = carry + incl - v;
+        cursor[b] = carry + incl - v;
+      }
+      carry += __shfl(incl, 63);
+      // compact list of non-empty bins, ascending
+      const unsigned long long nzm = __ballot(v > 0);
+      if (v > 0) nzlist[hdr[5] + __popcll(nzm & lt_mask)] = static_cast<uint16_t>(b);
+      if (lane == 0) hdr[5] += __popcll(nzm);
+      wave_sync();
+    }
+    if (lane == 0) bin_start[nb] = carry;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const uint32_t f = flags[c];
+    if (f & F_UNASSIGNED) {
+      const int b = static_cast<int>(meta[c] >> META_BIN_SHIFT) - 1;
+      if (b >= 0 && b < nb) order[atomicAdd(&cursor[b], 1)] = static_cast<uint16_t>(c);
+    }
+  }
+  __syncthreads();
+  const int planar_total = hdr[0];
+  t_p0 = DPX_STAMP();
+
+  // ---------------- P1: seeds + region growing, wave 0 only ---------------------------------------------
+  // cursor[b] now holds the END of bin b's (compacted) cell list; bin_start[b] its begin.
+  if (wid == 0) {
+    int remaining = planar_total;
+    int tail = 0, ngrow = 0, ncand = 0;
+    const int nnz = hdr[5];
+    const bool reg_bins = nnz <= 64;  // one non-empty bin per lane, kept in a register for the whole frame
+    const int mybin = (reg_bins && lane < nnz) ? static_cast<int>(nzlist[lane]) : -1;
+    // BFS lane constants: lane = (slot, dir); dir 0..3 = U, D, L, R
+    const int slot = lane >> 2, dir = lane & 3;
+    const int delta = dir == 0 ? -nh : (dir == 1 ? nh : (dir == 2 ? -1 : 1));
+    const uint32_t opp = static_cast<uint32_t>(dir ^ 1);
+    const uint32_t notme = ~(1u << opp) & 0xFu;
+    for (int guard = 0; remaining > 0 && guard <= C; ++guard) {
+      const unsigned long long ta = DPX_STAMP();
+      // most frequent bin, lowest index among maxima: key = count << 16 | (0xFFFF - bin)
+      uint32_t key = 0;
+      if (reg_bins) {
+        if (mybin >= 0) key = (static_cast<uint32_t>(hist[mybin]) << 16) | static_cast<uint32_t>(0xFFFF - mybin);
+      } else {
+        for (int t = lane; t < nnz; t += 64) {
+          const int b = nzlist[t];
+          const uint32_t k = (static_cast<uint32_t>(hist[b]) << 16) | static_cast<uint32_t>(0xFFFF - b);
+          key = k > key ? k : key;
+        }
+      }
+      key = wave_max_u32(key);
+      const int bv = static_cast<int>(key >> 16);
+      const int bb = 0xFFFF - static_cast<int>(key & 0xFFFFu);
+      if (bv <= 0) break;
+      if (static_cast<unsigned long long>(bv) < static_cast<unsigned long long>(static_cast<long long>(prm.min_cand))) break;
+      const unsigned long long tb = DPX_STAMP();
+      // min-MSE candidate, lowest cell id among equals; the scan compacts the bin's list (drops grown cells) in place
+      const int s = bin_start[bb], e = cursor[bb];
+      uint32_t bm = 0xFFFFFFFFu, bi = 0xFFFFFFFFu, anyc = 0xFFFFFFFFu;
+      int outp = s;
+      for (int base = s; base < e; base += 64) {
+        const int i = base + lane;
+        uint32_t c = 0;
+        bool alive = false;
+        if (i < e) {
+          c = order[i];
+          alive = (flags[c] & F_UNASSIGNED) != 0;
+        }
+        const unsigned long long am = __ballot(alive);
+        if (alive) {
+          order[outp + __popcll(am & lt_mask)] = static_cast<uint16_t>(c);
+          anyc = c < anyc ? c : anyc;
+          float m = FULL ? mse_l[c] : mse_c[c];
+          if (static_cast<double>(m) < 2147483647.0) {
+            m = m + 0.0f;  // -0 -> +0: the reference's float compare treats them as equal
+            const uint32_t om = ordered_f32(m);
+            if (om < bm || (om == bm && c < bi)) {
+              bm = om;
+              bi = c;
+            }
+          }
+        }
+        outp += __popcll(am);
+      }
+      if (lane == 0) cursor[bb] = outp;
+      const uint32_t gm = wave_min_u32(bm);
+      bi = wave_min_u32(bm == gm ? bi : 0xFFFFFFFFu);
+      const uint32_t seed = (gm != 0xFFFFFFFFu) ? bi : wave_min_u32(anyc);
+      if (seed == 0xFFFFFFFFu) break;
+
+      const unsigned long long tc = DPX_STAMP();
+      const int gstart = tail;
+      if (lane == 0) {
+        queue[tail] = static_cast<uint16_t>(seed);
+        qpos[seed] = static_cast<uint16_t>(tail);
+        flags[seed] = static_cast<uint8_t>(flags[seed] & ~F_UNASSIGNED);
+        atomicSub(&hist[bb], 1);  // hist.removePoint(seed); the seed's bin is bb
+      }
+      ++tail;
+      int head = gstart;
+      wave_sync();
+      while (head < tail) {
+        // Branch-free step: lane = (slot, dir).  All LDS reads are unconditional (clamped addresses), the decision is
+        // pure bit arithmetic: a single wave issues one instruction per ~4 cycles, so instruction count is latency.
+        const int nslots = (tail - head) < 16 ? (tail - head) : 16;
+        const int qi = head + (slot < nslots ? slot : 0);
+        const int u = queue[qi];
+        const int vraw = u + delta;
+        const bool inrange = (slot < nslots) && (vraw >= 0) && (vraw < C);
+        const int v = vraw < 0 ? 0 : (vraw >= C ? C - 1 : vraw);
+        const uint32_t fv = flags[v];
+        // positions of v's four neighbours in the queue (0xFFFF = never activated); out-of-grid neighbours are
+        // clamped to a valid address and are harmless because v's in-edge bit for them is 0 (k_cellgraph)
+        const int wU = v - nh > 0 ? v - nh : 0, wD = v + nh < C ? v + nh : C - 1;
+        const int wL = v - 1 > 0 ? v - 1 : 0, wR = v + 1 < C ? v + 1 : C - 1;
+        const uint32_t qU = qpos[wU], qD = qpos[wD], qL = qpos[wL], qR = qpos[wR];
+        const uint32_t uh = static_cast<uint32_t>(head), us = static_cast<uint32_t>(slot);
+        // bit k set: v's neighbour k sits EARLIER in this FIFO batch (queue position in [head, head + slot))
+        const uint32_t earlier = (((qU - uh) < us) ? 1u : 0u) | (((qD - uh) < us) ? 2u : 0u) |
+                                 (((qL - uh) < us) ? 4u : 0u) | (((qR - uh) < us) ? 8u : 0u);
+        const uint32_t inb = (fv >> 2) & 0xFu;  // in-edge bits of v
+        // u is v's neighbour number dir^1: v accepts u iff that in-edge is set; u loses to any OTHER in-neighbour
+        // that is earlier in the batch
+        const bool win = inrange && (fv & F_UNASSIGNED) && ((inb >> opp) & 1u) && ((inb & earlier & notme) == 0u);
+        const unsigned long long mask = __ballot(win);
+        if (win) {
+          const int pos = tail + __popcll(mask & lt_mask);
+          queue[pos] = static_cast<uint16_t>(v);
+          qpos[v] = static_cast<uint16_t>(pos);
+          flags[v] = static_cast<uint8_t>(fv & ~F_UNASSIGNED);
+          const int b = (FULL ? static_cast<int>(binof[v]) : static_cast<int>(meta[v] >> META_BIN_SHIFT)) - 1;
+          if (b >= 0 && b < nb) atomicSub(&hist[b], 1);  // hist.removePoint at activation time
+        }
+        tail += __popcll(mask);
+        head += nslots;
+        wave_sync();
+        if (DBG) ++n_steps;
+      }
+      const unsigned long long td = DPX_STAMP();
+      const int g = tail - gstart;
+      const bool is_cand = !(static_cast<unsigned long long>(g) < static_cast<unsigned long long>(static_cast<long long>(prm.min_cells))) &&
+                           ncand < rb.pcap;
+      if (lane == 0) {
+        grow_start[ngrow] = static_cast<uint32_t>(gstart);
+        if (is_cand) cand_grow[ncand] = static_cast<uint32_t>(ngrow);
+      }
+      ncand += is_cand;
+      ++ngrow;
+      remaining -= g;
+      if (DBG) {
+        const unsigned long long te = DPX_STAMP();
+        a_argmax += tb - ta; a_seed += tc - tb; a_bfs += td - tc; a_rem += te - td;
+      }
+    }
+    if (lane == 0) {
+      grow_start[ngrow] = static_cast<uint32_t>(tail);
+      hdr[1] = tail;
+      hdr[2] = ngrow;
+      hdr[3] = ncand;
+    }
+  }
+  __syncthreads();
+  const int activations = hdr[1], ngrow = hdr[2], ncand = hdr[3];
+  t_p1 = DPX_STAMP();
+
+  // ---------------- P2: exact float accumulation of every candidate segment (wave per segment) ------------
+  {
+    float* st = stage + wid * 64 * 9;
+    const float4* cf4 = reinterpret_cast<const float4*>(cells);
+    for (int ci = wid; ci < ncand; ci += 4) {
+      const int gi = static_cast<int>(cand_grow[ci]);
+      const int gs = static_cast<int>(grow_start[gi]), ge = static_cast<int>(grow_start[gi + 1]);
+      const int comp = lane < 9 ? lane : 0;
+      float acc = reinterpret_cast<const float*>(cells)[static_cast<size_t>(queue[gs]) * 16 + comp];  // the seed, counted twice
+      for (int base = gs; base < ge; base += 64) {
+        const int cnt = (ge - base) < 64 ? (ge - base) : 64;
+        if (lane < cnt) {
+          const size_t v = queue[base + lane];
+          const float4 a = cf4[v * 4 + 0], b4 = cf4[v * 4 + 1], c4 = cf4[v * 4 + 2];
+          float* d = st + lane * 9;
+          d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b4.x; d[5] = b4.y; d[6] = b4.z; d[7] = b4.w; d[8] = c4.x;
+        }
+        wave_sync();
+        if (lane < 9) {
+          int e2 = 0;
+          for (; e2 + 8 <= cnt; e2 += 8) {
+            float t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = st[(e2 + q) * 9 + comp];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc = acc + t[q];
+          }
+          for (; e2 < cnt; ++e2) acc = acc + st[e2 * 9 + comp];
+        }
+        wave_sync();
+      }
+      float* co = cand + static_cast<size_t>(ci) * 12;
+      if (lane < 9) co[lane] = acc;
+      if (lane == 9) co[9] = __int_as_float((ge - gs + 1) * prm.n);
+      if (lane == 10) co[10] = __int_as_float(gi);
+    }
+  }
+  __syncthreads();
+  t_p2 = DPX_STAMP();
+
+  // ---------------- P3: plane fit per candidate, thread-parallel; ordered ids ----------------------------
+  int nplanes = 0;
+  for (int base = 0; base < ncand; base += 256) {
+    const int ci = base + tid;
+    bool ok = false;
+    PlaneFit fit;
+    float s[3] = {0, 0, 0}, pp[6] = {0, 0, 0, 0, 0, 0};
+    int npts = 0, gi = 0;
+    float* co = cand + static_cast<size_t>(ci < ncand ? ci : 0) * 12;
+    if (ci < ncand) {
+      s[0] = co[0]; s[1] = co[1]; s[2] = co[2];
+      pp[0] = co[3]; pp[1] = co[4]; pp[2] = co[5]; pp[3] = co[6]; pp[4] = co[7]; pp[5] = co[8];
+      npts = __float_as_int(co[9]);
+      gi = __float_as_int(co[10]);
+      fit_plane(s, pp, npts, fit);
+      ok = fit.score > prm.min_score;
+    }
+    const unsigned long long mask = __ballot(ok);
+    if (lane == 0) hdr[8 + wid] = __popcll(mask);
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wid; ++w) off += hdr[8 + w];
+    const int total = hdr[8] + hdr[9] + hdr[10] + hdr[11];
+    const int id = nplanes + off + __popcll(mask & lt_mask);
+    if (ok) {
+      dpx_plane& pl = planes[id];
+      pl.sum[0] = s[0]; pl.sum[1] = s[1]; pl.sum[2] = s[2];
+      pl.pp[0] = pp[0]; pl.pp[1] = pp[1]; pl.pp[2] = pp[2]; pl.pp[3] = pp[3]; pl.pp[4] = pp[4]; pl.pp[5] = pp[5];
+      pl.mean[0] = fit.mean[0]; pl.mean[1] = fit.mean[1]; pl.mean[2] = fit.mean[2];
+      pl.normal[0] = fit.normal[0]; pl.normal[1] = fit.normal[1]; pl.normal[2] = fit.normal[2];
+      pl.d = fit.d; pl.mse = fit.mse; pl.score = fit.score;
+      pl.n_pts = npts;
+      pl.n_cells = static_cast<int>(grow_start[gi + 1] - grow_start[gi]);
+      pl.merge_label = id;
+      merge[id] = id;
+    }
+    if (ci < ncand) co[11] = __int_as_float(ok ? id + 1 : 0);
+    nplanes += total;
+    __syncthreads();
+  }
+
+  t_p3 = DPX_STAMP();
+  // ---------------- P4: labels_map_ ------------------------------------------------------------------------
+  for (int ci = wid; ci < ncand; ci += 4) {
+    const float* co = cand + static_cast<size_t>(ci) * 12;
+    const int id1 = __float_as_int(co[11]);
+    if (id1 == 0) continue;
+    const int gi = __float_as_int(co[10]);
+    const int gs = static_cast<int>(grow_start[gi]), ge = static_cast<int>(grow_start[gi + 1]);
+    for (int i = gs + lane; i < ge; i += 64) cell_labels[queue[i]] = id1;
+  }
+  __syncthreads();
+  t_p4 = DPX_STAMP();
+
+  // ---------------- P5: findMergedLabels, wave 0 ------------------------------------------------------------
+  // The adjacency pairs (packed a << 16 | b) and a 7-float view of every plane (normal, d, mean) are kept in LDS
+  // when they fit (they do unless a frame has thousands of planes); the plane records in global memory stay the
+  // source of truth for the sums and are what the caller reads back.
+  int merges = 0;
+  if (nplanes > 0 && wid == 0) {
+    uint32_t* lpairs = reinterpret_cast<uint32_t*>(stage);             // up to kPairCap packed pairs
+    constexpr int kPairCap = 1536;
+    uint32_t* bits = reinterpret_cast<uint32_t*>(stage) + kPairCap;    // 768 words = 24576 planes
+    float* pview = reinterpret_cast<float*>(qpos);                     // qpos|queue|order are dead: 6*C bytes
+    const bool lds_view = nplanes <= (6 * C) / 28 && nplanes <= 768 * 32 && nplanes < 65536;
+    int npairs = 0;
+    const int gw = nh - 1, gh = nv - 1;
+    const int total = gw > 0 && gh > 0 ? gw * gh : 0;
+    for (int base = 0; base < total; base += 64) {
+      const int idx = base + lane;
+      bool hp = false, vp = false;
+      int a = 0, right = 0, down = 0;
+      if (idx < total) {
+        const int r = idx / gw, c = idx - r * gw;
+        a = cell_labels[r * nh + c];
+        right = cell_labels[r * nh + c + 1];
+        down = cell_labels[(r + 1) * nh + c];
+        hp = a > 0 && right > 0 && a != right;
+        vp = a > 0 && down > 0 && a != down;
+        if (hp && r > 0 && cell_labels[(r - 1) * nh + c] == a && cell_labels[(r - 1) * nh + c + 1] == right) hp = false;
+        if (vp && c > 0 && cell_labels[r * nh + c - 1] == a && cell_labels[(r + 1) * nh + c - 1] == down) vp = false;
+      }
+      unsigned long long m1 = __ballot(hp);
+      if (hp) {
+        const int k = npairs + __popcll(m1 & lt_mask);
+        pairs[k] = make_uint2(static_cast<uint32_t>(a - 1), static_cast<uint32_t>(right - 1));
+        if (k < kPairCap) lpairs[k] = (static_cast<uint32_t>(a - 1) << 16) | static_cast<uint32_t>(right - 1);
+      }
+      npairs += __popcll(m1);
+      m1 = __ballot(vp);
+      if (vp) {
+        const int k = npairs + __popcll(m1 & lt_mask);
+        pairs[k] = make_uint2(static_cast<uint32_t>(a - 1), static_cast<uint32_t>(down - 1));
+        if (k < kPairCap) lpairs[k] = (static_cast<uint32_t>(a - 1) << 16) | static_cast<uint32_t>(down - 1);
+      }
+      npairs += __popcll(m1);
+    }
+    const bool lds_pairs = lds_view && npairs <= kPairCap;
+    if (lds_view)
+      for (int i = lane; i < nplanes; i += 64) {
+        const dpx_plane& pl = planes[i];
+        float* pv = pview + i * 7;
+        pv[0] = pl.normal[0]; pv[1] = pl.normal[1]; pv[2] = pl.normal[2]; pv[3] = pl.d;
+        pv[4] = pl.mean[0]; pv[5] = pl.mean[1]; pv[6] = pl.mean[2];
+      }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    wave_sync();
+    uint32_t* gbits = reinterpret_cast<uint32_t*>(mse_l);  // fallback bit row for huge plane counts (global-pairs path)
+    const int words = (nplanes + 31) >> 5;
+    uint32_t* rowbits = lds_view ? bits : (FULL && words <= C ? gbits : reinterpret_cast<uint32_t*>(qpos));
+    for (int row = 0; row < nplanes; ++row) {
+      for (int w = lane; w < words; w += 64) rowbits[w] = 0;
+      wave_sync();
+      if (lds_pairs) {
+        for (int i = lane; i < npairs; i += 64) {
+          const uint32_t p = lpairs[i];
+          const int px = static_cast<int>(p >> 16), py = static_cast<int>(p & 0xFFFFu);
+          if (px == row) atomicOr(&rowbits[py >> 5], 1u << (py & 31));
+          if (py == row) atomicOr(&rowbits[px >> 5], 1u << (px & 31));
+        }
+      } else {
+        for (int i = lane; i < npairs; i += 64) {
+          const uint2 p = pairs[i];
+          if (static_cast<int>(p.x) == row) atomicOr(&rowbits[p.y >> 5], 1u << (p.y & 31));
+          if (static_cast<int>(p.y) == row) atomicOr(&rowbits[p.x >> 5], 1u << (p.x & 31));
+        }
+      }
+      wave_sync();
+      const int pid = merge[row];
+      float pnx, pny, pnz, pd;
+      if (lds_view) {
+        const float* pv = pview + pid * 7;
+        pnx = pv[0]; pny = pv[1]; pnz = pv[2]; pd = pv[3];
+      } else {
+        const dpx_plane& pp_ = planes[pid];
+        pnx = pp_.normal[0]; pny = pp_.normal[1]; pnz = pp_.normal[2]; pd = pp_.d;
+      }
+      bool expanded = false;
+      for (int cbase = row + 1; cbase < nplanes; cbase += 64) {
+        const int col = cbase + lane;
+        bool acc = false;
+        if (col < nplanes && ((rowbits[col >> 5] >> (col & 31)) & 1u)) {
+          float cnx, cny, cnz, cmx, cmy, cmz;
+          if (lds_view) {
+            const float* cv = pview + col * 7;
+            cnx = cv[0]; cny = cv[1]; cnz = cv[2]; cmx = cv[4]; cmy = cv[5]; cmz = cv[6];
+          } else {
+            const dpx_plane& pc = planes[col];
+            cnx = pc.normal[0]; cny = pc.normal[1]; cnz = pc.normal[2]; cmx = pc.mean[0]; cmy = pc.mean[1]; cmz = pc.mean[2];
+          }
+          const float cosv = dot3(pnx, pny, pnz, cnx, cny, cnz);
+          const float tf = dot3(pnx, pny, pnz, cmx, cmy, cmz) + pd;  // float add (plane_extractor.cpp:410-411)
+          const double dist = static_cast<double>(tf) * static_cast<double>(tf);
+          acc = static_cast<double>(cosv) > static_cast<double>(prm.min_cos) && dist < static_cast<double>(prm.max_merge_dist);
+        }
+        unsigned long long mask = __ballot(acc);
+        while (mask) {
+          const int l = __builtin_ctzll(mask);
+          mask &= mask - 1;
+          const int colx = cbase + l;
+          float* pf = reinterpret_cast<float*>(&planes[pid]);
+          const float* cfp = reinterpret_cast<const float*>(&planes[colx]);
+          if (lane < 9) pf[lane] = pf[lane] + cfp[lane];
+          if (lane == 9) planes[pid].n_pts += planes[colx].n_pts;
+          if (lane == 10) merge[colx] = pid;
+          expanded = true;
+          ++merges;
+        }
+      }
+      if (expanded) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        wave_sync();
+        if (lane == 0) {
+          dpx_plane& pl = planes[pid];
+          PlaneFit fit;
+          fit_plane(pl.sum, pl.pp, pl.n_pts, fit);
+          pl.mean[0] = fit.mean[0]; pl.mean[1] = fit.mean[1]; pl.mean[2] = fit.mean[2];
+          pl.normal[0] = fit.normal[0]; pl.normal[1] = fit.normal[1]; pl.normal[2] = fit.normal[2];
+          pl.d = fit.d; pl.mse = fit.mse; pl.score = fit.score;
+          if (lds_view) {
+            float* pv = pview + pid * 7;
+            pv[0] = fit.normal[0]; pv[1] = fit.normal[1]; pv[2] = fit.normal[2]; pv[3] = fit.d;
+            pv[4] = fit.mean[0]; pv[5] = fit.mean[1]; pv[6] = fit.mean[2];
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      }
+      wave_sync();
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  }
+  __syncthreads();
+  t_p5 = DPX_STAMP();
+  // ---------------- P6: merged label per cell; records -------------------------------------------------------
+  if (nplanes > 0) {
+    for (int c = tid; c < C; c += 256) {
+      const int L = cell_labels[c];
+      cell_labels[c] = L == 0 ? 0 : merge[L - 1] + 1;
+    }
+    for (int i = tid; i < nplanes; i += 256) planes[i].merge_label = merge[i];
+  }
+  if (tid == 0) {
+    dpx_frame_stats st;
+    st.planar_cells = planar_total;
+    st.grows = ngrow;
+    st.activations = activations;
+    st.segments = nplanes;
+    st.merges = merges;
+    st.overflow = 0;
+    rb.stats[frame] = st;
+    if (DBG && rx.dbg) {
+      unsigned long long* d = rx.dbg + static_cast<size_t>(frame) * 16;
+      const unsigned long long t_end = DPX_STAMP();
+      d[0] = t_p0 - t_start; d[1] = t_p1 - t_p0; d[2] = t_p2 - t_p1; d[3] = t_p3 - t_p2; d[4] = t_p4 - t_p3;
+      d[5] = t_p5 - t_p4; d[6] = t_end - t_p5; d[7] = t_end - t_start;
+      d[8] = a_argmax; d[9] = a_seed; d[10] = a_bfs; d[11] = a_rem; d[12] = n_steps; d[13] = ngrow; d[14] = ncand; d[15] = activations;
+    }
+  }
+}
+#undef DPX_STAMP
+
+}  // namespace dpx

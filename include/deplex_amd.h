@@ -162,6 +162,12 @@ int dpx_time_planefit(dpx_handle h, const void* d_in, int32_t input_kind, int32_
 /* Algorithmic bytes one plane-fit launch moves for `batch` frames (input + cell records). */
 int64_t dpx_planefit_bytes(dpx_handle h, int32_t input_kind, int32_t batch);
 
+/* Diagnostic build of the region-growing kernel: shader-clock cycles per phase of frame `frame` of the last call
+ * (out16: P0 state load, P1 seeds+BFS, P2 accumulate, P3 fits, P4 labels, P5 merge, P6 final, total, then the
+ * sums over grows of arg-max, seed search, BFS, histogram removal, and the counters BFS steps, grows, candidates,
+ * activations).  enable != 0 switches the diagnostic instantiation on for later calls; never used when timing. */
+int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_t* out16);
+
 /* Exercises dpx_math.h and the 3x3 eigensolver on the device (parity tests): n inputs each.
  * which: 0 atan2(a,b) 1 sin(a) 2 cos(a) 3 acos(a) 4 sqrt(a).  Host pointers. */
 int dpx_test_math(int32_t which, const double* a, const double* b, double* out, int64_t n, int32_t device);

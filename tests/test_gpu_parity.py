@@ -181,17 +181,34 @@ def test_ragged_and_tiny_images(D, oracle):
         full_compare(D, oracle, depth, synth.intrinsics_for(h, w), oracle.default_config())
 
 
-def test_global_state_variant(D, oracle):
-    """The region-growing kernel keeps its per-cell state in LDS when it fits and in global memory otherwise;
-    force the global variant on a small frame to check it."""
-    os.environ["DPX_FORCE_GLOBAL_STATE"] = "1"
+@pytest.mark.parametrize("env", ["DPX_FORCE_GLOBAL_STATE", "DPX_REGIONS_V1", "DPX_REGIONS_LEAN", "DPX_NO_FASTDIV", "DPX_PLANEFIT_V1"])
+def test_kernel_variants(D, oracle, env):
+    """Every kernel variant must give the same bits: region growing with its per-cell state in global memory
+    (used when a frame does not fit LDS), the v1 single-wave kernel, the lean LDS tier (mse/bin read from global),
+    the plane-fit kernel with IEEE division instead of the verified reciprocal sequence, and the generic v1
+    plane-fit kernel."""
+    os.environ[env] = "1"
     try:
         depth = synth.synth_batch(3, 240, 320, seed0=7)
         full_compare(D, oracle, depth, synth.intrinsics_for(240, 320), oracle.default_config())
-        full_compare(D, oracle, synth.tum_stream(2), tuple(float(v) for v in np.array(synth.read_K(synth.TUM_K))[[0, 1, 0, 1], [0, 1, 2, 2]]),
+        K = synth.read_K(synth.TUM_K)
+        full_compare(D, oracle, synth.tum_stream(2), tuple(float(v) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2])),
                      oracle.default_config())
+        Ki = synth.read_K(synth.ICL_K)
+        full_compare(D, oracle, synth.load_png_u16(synth.ICL_PNG)[None], tuple(float(v) for v in (Ki[0, 0], Ki[1, 1], Ki[0, 2], Ki[1, 2])),
+                     oracle.config_from_ini(synth.ICL_INI))
     finally:
-        del os.environ["DPX_FORCE_GLOBAL_STATE"]
+        del os.environ[env]
+
+
+def test_fast_division_is_verified(D):
+    """The reciprocal division of the fast plane-fit kernel is accepted only after an exhaustive device-side check
+    against IEEE division for the frame geometry; the fixtures' intrinsics (including ICL's negative fy) pass it."""
+    ex = D.PlaneExtractor(480, 640)
+    Kt, Ki = synth.read_K(synth.TUM_K), synth.read_K(synth.ICL_K)
+    assert ex.prepare_intrinsics(float(Kt[0, 0]), float(Kt[1, 1]), float(Kt[0, 2]), float(Kt[1, 2])) is True
+    assert ex.prepare_intrinsics(float(Ki[0, 0]), float(Ki[1, 1]), float(Ki[0, 2]), float(Ki[1, 2])) is True
+    assert ex.prepare_intrinsics(*synth.intrinsics_for(480, 640)) is True
 
 
 def test_tum_stream_batch64_properties(D, oracle):

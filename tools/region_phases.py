@@ -1,0 +1,23 @@
+"""Diagnostic: per-phase shader-clock cycles of the region-growing kernel on the bench workload (one frame)."""
+import sys
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import deplex_amd as D
+from deplex_amd import _capi
+import synth
+
+depth = synth.tum_stream(64)
+K = synth.read_K(synth.TUM_K)
+intr = tuple(float(v) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2]))
+ex = D.PlaneExtractor(480, 640, max_batch=64)
+_capi.check(_capi.lib().dpx_debug_region_phases(ex._h, 1, 0, None))
+for rep in range(2):
+    ex.process_depth_batch(depth, *intr)
+names = ["P0 load", "P1 seeds+bfs", "P2 accum", "P3 fits", "P4 labels", "P5 merge", "P6 final", "total",
+         "sum argmax", "sum seed", "sum bfs", "sum removal", "bfs steps", "grows", "cands", "activations"]
+for f in (0, 1, 17):
+    out = np.zeros(16, dtype=np.uint64)
+    _capi.check(_capi.lib().dpx_debug_region_phases(ex._h, 1, f, out.ctypes.data))
+    print(f"frame {f}: " + ", ".join(f"{n}={int(v)}" for n, v in zip(names, out)))
