@@ -19,6 +19,10 @@ from pathlib import Path
 
 import numpy as np
 
+# HIP maps streams onto at most GPU_MAX_HW_QUEUES hardware queues (default 4); the bench keeps 16 batches in flight so
+# that the latency-bound region-growing kernel of one batch overlaps the bandwidth/ALU-bound kernels of the others.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
@@ -83,10 +87,10 @@ def cpu_baseline(depth, intr, cores: int, budget_s: float = 15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("DPX_BENCH_STREAMS", 4)))
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("DPX_BENCH_STREAMS", 16)))
     ap.add_argument("--workload", default="tum_stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-frames", type=int, default=4)

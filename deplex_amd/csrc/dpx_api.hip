@@ -218,7 +218,7 @@ int run_pipeline(dpx_handle h, const void* d_in, bool depth, int batch, float fx
   }
   if (prof) DPX_HIP(hipEventRecord(ev[1], s));
   const long long total = static_cast<long long>(batch) * prm.C;
-  if (total > 0)
+  if (total > 0 && h->regions_tier != 2)  // the FULL-tier region kernel computes the cell graph itself
     hipLaunchKernelGGL(dpx::k_cellgraph, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, prm, h->d_cells, h->d_meta, h->d_mse_c);
   if (prof) DPX_HIP(hipEventRecord(ev[2], s));
   dpx::RegionBufs rb{};
@@ -228,11 +228,11 @@ int run_pipeline(dpx_handle h, const void* d_in, bool depth, int batch, float fx
   rb.g_queue = h->d_gqueue; rb.pcap = h->pcap;
   dpx::Regions2Extra rx{h->d_mse_c, h->d_cand_grow, h->d_dbg};
   if (h->regions_tier == 2 && h->d_dbg)
-    hipLaunchKernelGGL((dpx::k_regions2<true, true>), dim3(batch), dim3(256), h->lds2_bytes, s, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<true, true>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
   else if (h->regions_tier == 2)
-    hipLaunchKernelGGL((dpx::k_regions2<true, false>), dim3(batch), dim3(256), h->lds2_bytes, s, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<true, false>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
   else if (h->regions_tier == 1)
-    hipLaunchKernelGGL((dpx::k_regions2<false, false>), dim3(batch), dim3(256), h->lds2_bytes, s, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<false, false>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
   else if (h->use_lds)
     hipLaunchKernelGGL(dpx::k_regions<true>, dim3(batch), dim3(64), h->lds_bytes, s, prm, rb);
   else
@@ -459,7 +459,7 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
                                                       : static_cast<long long>(C) / cfg->min_region_growing_cells_activated));
   {
     // region-growing kernel tier: everything in LDS (13 B/cell), lean (7 B/cell), or the v1 kernel
-    const size_t fixed = 64 + hist_bytes + 4 * 64 * 9 * 4 + 64;
+    const size_t fixed = 192 + hist_bytes + static_cast<size_t>(dpx::kRW) * 64 * 9 * 4 + 64;
     const char* v1 = std::getenv("DPX_REGIONS_V1");
     const char* lean = std::getenv("DPX_REGIONS_LEAN");
     h->regions_tier = 0;
@@ -614,6 +614,13 @@ int dpx_get_cell_edges(dpx_handle h, int32_t frame, uint8_t* out) {
   DPX_CHECK_FRAME();
   const size_t C = h->prm.C;
   std::vector<uint32_t> tmp(C);
+  if (C && h->regions_tier == 2) {  // the fused path never materialises the cell graph: compute it on demand
+    dpx::Params prm = h->prm;
+    prm.batch = h->last_batch;
+    const long long total = static_cast<long long>(prm.batch) * prm.C;
+    hipLaunchKernelGGL(dpx::k_cellgraph, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, h->last_stream, prm, h->d_cells, h->d_meta, h->d_mse_c);
+    DPX_HIP(hipStreamSynchronize(h->last_stream));
+  }
   if (C) DPX_HIP(hipMemcpy(tmp.data(), h->d_meta + frame * C, C * 4, hipMemcpyDeviceToHost));
   for (size_t i = 0; i < C; ++i) out[i] = static_cast<uint8_t>(tmp[i] & 0x3F);
   return DPX_OK;

@@ -1,4 +1,4 @@
-// dpx_regions2.h — K4+K5, second generation: one 256-thread workgroup per frame.
+// dpx_regions2.h — K4+K5, second generation: one workgroup (DPX_RT threads) per frame.
 //
 // Same algorithm and the same bit-exact results as dpx_regions.h (kept as the fallback for frames whose state does
 // not fit LDS); what changes is where the time goes:
@@ -48,6 +48,12 @@ __device__ __forceinline__ uint32_t ordered_f32(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+#ifndef DPX_RT
+#define DPX_RT 512
+#endif
+constexpr int kRT = DPX_RT;        // threads per frame workgroup
+constexpr int kRW = DPX_RT / 64;   // waves
+
 struct Regions2Extra {
   const float* mse_c;   // [B][C] compact per-cell mse (k_cellgraph output)
   uint32_t* cand_grow;  // [B][pcap] grow index of each candidate segment
@@ -58,7 +64,7 @@ struct Regions2Extra {
 
 // DBG = true is a separate diagnostic instantiation (phase timing through s_memtime); production uses DBG = false.
 template <bool FULL, bool DBG>
-__global__ __launch_bounds__(256) void k_regions2(Params prm, RegionBufs rb, Regions2Extra rx) {
+__global__ __launch_bounds__(kRT) void k_regions2(Params prm, RegionBufs rb, Regions2Extra rx) {
   unsigned long long t_start = DPX_STAMP(), t_p0 = 0, t_p1 = 0, t_p2 = 0, t_p3 = 0, t_p4 = 0, t_p5 = 0;
   unsigned long long a_argmax = 0, a_seed = 0, a_bfs = 0, a_rem = 0, n_steps = 0;
   const int frame = blockIdx.x;
@@ -68,12 +74,12 @@ __global__ __launch_bounds__(256) void k_regions2(Params prm, RegionBufs rb, Reg
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
   extern __shared__ __align__(16) unsigned char smem[];
-  int* hdr = reinterpret_cast<int*>(smem);  // 16 ints: 0 planar count, 1 tail, 2 ngrow, 3 ncand, 4 nplanes, 8..11 wave counts
-  int* hist = hdr + 16;
+  int* hdr = reinterpret_cast<int*>(smem);  // 48 ints: 0 planar count, 1 tail, 2 ngrow, 3 ncand, 5 nnz bins, 16.. wave counts
+  int* hist = hdr + 48;
   int* bin_start = hist + nb;        // nb + 1
   int* cursor = bin_start + nb + 1;  // nb
-  float* stage = reinterpret_cast<float*>(cursor + nb);  // 4 waves x 64 entries x 9 floats
-  float* mse_l = stage + 4 * 64 * 9;                     // FULL: C floats
+  float* stage = reinterpret_cast<float*>(cursor + nb);  // kRW waves x 64 entries x 9 floats (>= 2304 floats)
+  float* mse_l = stage + kRW * 64 * 9;                     // FULL: C floats
   uint16_t* qpos = reinterpret_cast<uint16_t*>(mse_l + (FULL ? C : 0));
   uint16_t* queue = qpos + C;
   uint16_t* order = queue + C;
@@ -94,24 +100,54 @@ __global__ __launch_bounds__(256) void k_regions2(Params prm, RegionBufs rb, Reg
   int32_t* merge = rb.merge + static_cast<size_t>(frame) * rb.pcap;
 
   // ---------------- P0: state into LDS, histogram, bin-grouped order ------------------------------------
-  for (int b = tid; b < nb; b += 256) hist[b] = 0;
-  if (tid < 16) hdr[tid] = 0;
+  for (int b = tid; b < nb; b += kRT) hist[b] = 0;
+  if (tid < 48) hdr[tid] = 0;
   __syncthreads();
   {
     int planar_cnt = 0;
-    for (int c = tid; c < C; c += 256) {
-      const uint32_t m = meta[c];
-      // LDS flag byte: bit 0 unassigned, bits 2..5 IN-edges (neighbour U/D/L/R of this cell may activate it)
-      flags[c] = static_cast<uint8_t>((m & F_UNASSIGNED) | (((m >> 8) & 0xFu) << 2));
-      qpos[c] = 0xFFFFu;
-      cell_labels[c] = 0;
+    for (int c = tid; c < C; c += kRT) {
+      uint32_t fl, bin1;
       if (FULL) {
-        binof[c] = static_cast<uint16_t>(m >> META_BIN_SHIFT);
-        mse_l[c] = mse_c[c];
+        // fused K3 (k_cellgraph): planar bit, histogram bin and the four IN-edges of the growSeed predicate
+        // (plane_extractor.cpp:377-383) straight from the plane-fit records; no meta/mse round trip through HBM
+        const float4* rc = reinterpret_cast<const float4*>(cells + c);
+        const float4 q2 = rc[2], q3 = rc[3];  // {pp5, n0, n1, n2}, {d, mse, tol, info}
+        const uint32_t info = __float_as_uint(q3.w);
+        fl = (info & CELL_PLANAR) ? F_UNASSIGNED : 0u;
+        bin1 = (info & CELL_PLANAR) ? (info >> 8) : 0u;
+        if (fl) {
+          const float4 q0 = rc[0];
+          const float nf = static_cast<float>(prm.n);
+          const float smx = q0.x / nf, smy = q0.y / nf, smz = q0.z / nf;  // mean_ = coord_sum_ / nr_pts_
+          const double tol_self = static_cast<double>(q3.z);
+          const int cr = c / nh, cc = c - cr * nh;
+          const int nbr[4] = {cr >= 1 ? c - nh : -1, cr + 1 < nv ? c + nh : -1, cc >= 1 ? c - 1 : -1, cc + 1 < nh ? c + 1 : -1};
+#pragma unroll
+          for (int dir = 0; dir < 4; ++dir) {
+            const int v = nbr[dir];
+            if (v < 0) continue;
+            const float4* rv = reinterpret_cast<const float4*>(cells + v);
+            const float4 v2 = rv[2], v3 = rv[3];
+            if (!(__float_as_uint(v3.w) & CELL_PLANAR)) continue;
+            const float cosf_ = dot3(q2.y, q2.z, q2.w, v2.y, v2.z, v2.w);  // same products/sum order as n_v . n_c
+            if (!(static_cast<double>(cosf_) >= static_cast<double>(prm.min_cos))) continue;
+            const double ti = static_cast<double>(dot3(v2.y, v2.z, v2.w, smx, smy, smz)) + static_cast<double>(v3.x);
+            if (ti * ti <= tol_self) fl |= (F_EDGE0 << dir);
+          }
+        }
+        binof[c] = static_cast<uint16_t>(bin1);
+        mse_l[c] = q3.y;
+      } else {
+        const uint32_t m = meta[c];
+        // LDS flag byte: bit 0 unassigned, bits 2..5 IN-edges (neighbour U/D/L/R of this cell may activate it)
+        fl = (m & F_UNASSIGNED) | (((m >> 8) & 0xFu) << 2);
+        bin1 = m >> META_BIN_SHIFT;
       }
-      if (m & F_UNASSIGNED) {
+      flags[c] = static_cast<uint8_t>(fl);
+      qpos[c] = 0xFFFFu;
+      if (fl & F_UNASSIGNED) {
         ++planar_cnt;
-        const int b = static_cast<int>(m >> META_BIN_SHIFT) - 1;
+        const int b = static_cast<int>(bin1) - 1;
         if (b >= 0 && b < nb) atomicAdd(&hist[b], 1);
       }
     }
@@ -139,10 +175,10 @@ __global__ __launch_bounds__(256) void k_regions2(Params prm, RegionBufs rb, Reg
     if (lane == 0) bin_start[nb] = carry;
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
+  for (int c = tid; c < C; c += kRT) {
     const uint32_t f = flags[c];
     if (f & F_UNASSIGNED) {
-      const int b = static_cast<int>(meta[c] >> META_BIN_SHIFT) - 1;
+      const int b = (FULL ? static_cast<int>(binof[c]) : static_cast<int>(meta[c] >> META_BIN_SHIFT)) - 1;
       if (b >= 0 && b < nb) order[atomicAdd(&cursor[b], 1)] = static_cast<uint16_t>(c);
     }
   }
@@ -248,8 +284,10 @@ __global__ __launch_bounds__(256) void k_regions2(Params prm, RegionBufs rb, Reg
                                  (((qL - uh) < us) ? 4u : 0u) | (((qR - uh) < us) ? 8u : 0u);
         const uint32_t inb = (fv >> 2) & 0xFu;  // in-edge bits of v
         // u is v's neighbour number dir^1: v accepts u iff that in-edge is set; u loses to any OTHER in-neighbour
-        // that is earlier in the batch
-        const bool win = inrange && (fv & F_UNASSIGNED) && ((inb >> opp) & 1u) && ((inb & earlier & notme) == 0u);
+        // that is earlier in the batch.  Integer logic only (no short-circuit): keeps the five LDS reads above in
+        // one batch instead of three dependent round trips.
+        const uint32_t okbits = (inrange ? 1u : 0u) & fv & (inb >> opp) & (((inb & earlier & notme) == 0u) ? 1u : 0u);
+        const bool win = okbits != 0u;
         const unsigned long long mask = __ballot(win);
         if (win) {
           const int pos = tail + __popcll(mask & lt_mask);
@@ -291,11 +329,14 @@ __global__ __launch_bounds__(256) void k_regions2(Params prm, RegionBufs rb, Reg
   const int activations = hdr[1], ngrow = hdr[2], ncand = hdr[3];
   t_p1 = DPX_STAMP();
 
+  // `order` is dead after the seed loop: it becomes the uint16 label map of P4/P5 (labels_map_)
+  uint16_t* lab16 = order;
+  for (int c = tid; c < C; c += kRT) lab16[c] = 0;
   // ---------------- P2: exact float accumulation of every candidate segment (wave per segment) ------------
   {
     float* st = stage + wid * 64 * 9;
     const float4* cf4 = reinterpret_cast<const float4*>(cells);
-    for (int ci = wid; ci < ncand; ci += 4) {
+    for (int ci = wid; ci < ncand; ci += kRW) {
       const int gi = static_cast<int>(cand_grow[ci]);
       const int gs = static_cast<int>(grow_start[gi]), ge = static_cast<int>(grow_start[gi + 1]);
       const int comp = lane < 9 ? lane : 0;
@@ -333,7 +374,7 @@ __global__ __launch_bounds__(256) void k_regions2(Params prm, RegionBufs rb, Reg
 
   // ---------------- P3: plane fit per candidate, thread-parallel; ordered ids ----------------------------
   int nplanes = 0;
-  for (int base = 0; base < ncand; base += 256) {
+  for (int base = 0; base < ncand; base += kRT) {
     const int ci = base + tid;
     bool ok = false;
     PlaneFit fit;
@@ -349,11 +390,14 @@ __global__ __launch_bounds__(256) void k_regions2(Params prm, RegionBufs rb, Reg
       ok = fit.score > prm.min_score;
     }
     const unsigned long long mask = __ballot(ok);
-    if (lane == 0) hdr[8 + wid] = __popcll(mask);
+    if (lane == 0) hdr[16 + wid] = __popcll(mask);
     __syncthreads();
-    int off = 0;
-    for (int w = 0; w < wid; ++w) off += hdr[8 + w];
-    const int total = hdr[8] + hdr[9] + hdr[10] + hdr[11];
+    int off = 0, total = 0;
+    for (int w = 0; w < kRW; ++w) {
+      const int cw = hdr[16 + w];
+      off += w < wid ? cw : 0;
+      total += cw;
+    }
     const int id = nplanes + off + __popcll(mask & lt_mask);
     if (ok) {
       dpx_plane& pl = planes[id];
@@ -374,94 +418,105 @@ __global__ __launch_bounds__(256) void k_regions2(Params prm, RegionBufs rb, Reg
 
   t_p3 = DPX_STAMP();
   // ---------------- P4: labels_map_ ------------------------------------------------------------------------
-  for (int ci = wid; ci < ncand; ci += 4) {
+  for (int ci = wid; ci < ncand; ci += kRW) {
     const float* co = cand + static_cast<size_t>(ci) * 12;
     const int id1 = __float_as_int(co[11]);
     if (id1 == 0) continue;
     const int gi = __float_as_int(co[10]);
     const int gs = static_cast<int>(grow_start[gi]), ge = static_cast<int>(grow_start[gi + 1]);
-    for (int i = gs + lane; i < ge; i += 64) cell_labels[queue[i]] = id1;
+    for (int i = gs + lane; i < ge; i += 64) lab16[queue[i]] = static_cast<uint16_t>(id1);
   }
   __syncthreads();
   t_p4 = DPX_STAMP();
 
   // ---------------- P5: findMergedLabels, wave 0 ------------------------------------------------------------
-  // The adjacency pairs (packed a << 16 | b) and a 7-float view of every plane (normal, d, mean) are kept in LDS
-  // when they fit (they do unless a frame has thousands of planes); the plane records in global memory stay the
-  // source of truth for the sums and are what the caller reads back.
+  // Fast path (plane count up to a few hundred): the symmetric adjacency bit matrix, a 7-float view of every plane
+  // (normal, d, mean) and the merge labels live in LDS.  Otherwise: adjacency pair list in global memory, one bit
+  // row rebuilt per plane (as in dpx_regions.h).
   int merges = 0;
   if (nplanes > 0 && wid == 0) {
-    uint32_t* lpairs = reinterpret_cast<uint32_t*>(stage);             // up to kPairCap packed pairs
-    constexpr int kPairCap = 1536;
-    uint32_t* bits = reinterpret_cast<uint32_t*>(stage) + kPairCap;    // 768 words = 24576 planes
-    float* pview = reinterpret_cast<float*>(qpos);                     // qpos|queue|order are dead: 6*C bytes
-    const bool lds_view = nplanes <= (6 * C) / 28 && nplanes <= 768 * 32 && nplanes < 65536;
-    int npairs = 0;
+    const int wpr = (nplanes + 31) >> 5;  // words per matrix row
+    constexpr int kMatWords = 2304;       // stage holds at least 2304 words
+    uint32_t* mat = reinterpret_cast<uint32_t*>(stage);
+    float* pview = reinterpret_cast<float*>(qpos);                   // qpos|queue are dead: 4*C bytes
+    int32_t* lmerge = reinterpret_cast<int32_t*>(pview + 7 * nplanes);
+    const bool fast = nplanes * 32 <= 4 * C && nplanes * wpr <= kMatWords;
     const int gw = nh - 1, gh = nv - 1;
     const int total = gw > 0 && gh > 0 ? gw * gh : 0;
-    for (int base = 0; base < total; base += 64) {
-      const int idx = base + lane;
-      bool hp = false, vp = false;
-      int a = 0, right = 0, down = 0;
-      if (idx < total) {
-        const int r = idx / gw, c = idx - r * gw;
-        a = cell_labels[r * nh + c];
-        right = cell_labels[r * nh + c + 1];
-        down = cell_labels[(r + 1) * nh + c];
-        hp = a > 0 && right > 0 && a != right;
-        vp = a > 0 && down > 0 && a != down;
-        if (hp && r > 0 && cell_labels[(r - 1) * nh + c] == a && cell_labels[(r - 1) * nh + c + 1] == right) hp = false;
-        if (vp && c > 0 && cell_labels[r * nh + c - 1] == a && cell_labels[(r + 1) * nh + c - 1] == down) vp = false;
-      }
-      unsigned long long m1 = __ballot(hp);
-      if (hp) {
-        const int k = npairs + __popcll(m1 & lt_mask);
-        pairs[k] = make_uint2(static_cast<uint32_t>(a - 1), static_cast<uint32_t>(right - 1));
-        if (k < kPairCap) lpairs[k] = (static_cast<uint32_t>(a - 1) << 16) | static_cast<uint32_t>(right - 1);
-      }
-      npairs += __popcll(m1);
-      m1 = __ballot(vp);
-      if (vp) {
-        const int k = npairs + __popcll(m1 & lt_mask);
-        pairs[k] = make_uint2(static_cast<uint32_t>(a - 1), static_cast<uint32_t>(down - 1));
-        if (k < kPairCap) lpairs[k] = (static_cast<uint32_t>(a - 1) << 16) | static_cast<uint32_t>(down - 1);
-      }
-      npairs += __popcll(m1);
-    }
-    const bool lds_pairs = lds_view && npairs <= kPairCap;
-    if (lds_view)
+    int npairs = 0;
+    if (fast) {
+      for (int w = lane; w < nplanes * wpr; w += 64) mat[w] = 0;
       for (int i = lane; i < nplanes; i += 64) {
         const dpx_plane& pl = planes[i];
         float* pv = pview + i * 7;
         pv[0] = pl.normal[0]; pv[1] = pl.normal[1]; pv[2] = pl.normal[2]; pv[3] = pl.d;
         pv[4] = pl.mean[0]; pv[5] = pl.mean[1]; pv[6] = pl.mean[2];
+        lmerge[i] = i;
       }
+      wave_sync();
+      // getConnectedComponents (plane_extractor.cpp:430-453): rows 0..nv-2 x cols 0..nh-2, right and down neighbour,
+      // symmetrised
+      for (int base = 0; base < total; base += 64) {
+        const int idx = base + lane;
+        if (idx < total) {
+          const int r = idx / gw, c = idx - r * gw;
+          const int a = lab16[r * nh + c];
+          const int right = lab16[r * nh + c + 1];
+          const int down = lab16[(r + 1) * nh + c];
+          if (a > 0 && right > 0 && a != right) {
+            atomicOr(&mat[(a - 1) * wpr + ((right - 1) >> 5)], 1u << ((right - 1) & 31));
+            atomicOr(&mat[(right - 1) * wpr + ((a - 1) >> 5)], 1u << ((a - 1) & 31));
+          }
+          if (a > 0 && down > 0 && a != down) {
+            atomicOr(&mat[(a - 1) * wpr + ((down - 1) >> 5)], 1u << ((down - 1) & 31));
+            atomicOr(&mat[(down - 1) * wpr + ((a - 1) >> 5)], 1u << ((a - 1) & 31));
+          }
+        }
+      }
+    } else {
+      for (int base = 0; base < total; base += 64) {
+        const int idx = base + lane;
+        bool hp = false, vp = false;
+        int a = 0, right = 0, down = 0;
+        if (idx < total) {
+          const int r = idx / gw, c = idx - r * gw;
+          a = lab16[r * nh + c];
+          right = lab16[r * nh + c + 1];
+          down = lab16[(r + 1) * nh + c];
+          hp = a > 0 && right > 0 && a != right;
+          vp = a > 0 && down > 0 && a != down;
+          if (hp && r > 0 && lab16[(r - 1) * nh + c] == a && lab16[(r - 1) * nh + c + 1] == right) hp = false;
+          if (vp && c > 0 && lab16[r * nh + c - 1] == a && lab16[(r + 1) * nh + c - 1] == down) vp = false;
+        }
+        unsigned long long m1 = __ballot(hp);
+        if (hp) pairs[npairs + __popcll(m1 & lt_mask)] = make_uint2(static_cast<uint32_t>(a - 1), static_cast<uint32_t>(right - 1));
+        npairs += __popcll(m1);
+        m1 = __ballot(vp);
+        if (vp) pairs[npairs + __popcll(m1 & lt_mask)] = make_uint2(static_cast<uint32_t>(a - 1), static_cast<uint32_t>(down - 1));
+        npairs += __popcll(m1);
+      }
+    }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     wave_sync();
-    uint32_t* gbits = reinterpret_cast<uint32_t*>(mse_l);  // fallback bit row for huge plane counts (global-pairs path)
-    const int words = (nplanes + 31) >> 5;
-    uint32_t* rowbits = lds_view ? bits : (FULL && words <= C ? gbits : reinterpret_cast<uint32_t*>(qpos));
+    uint32_t* slowbits = reinterpret_cast<uint32_t*>(qpos);  // slow path bit row: 4*C bytes >= nplanes bits
     for (int row = 0; row < nplanes; ++row) {
-      for (int w = lane; w < words; w += 64) rowbits[w] = 0;
-      wave_sync();
-      if (lds_pairs) {
-        for (int i = lane; i < npairs; i += 64) {
-          const uint32_t p = lpairs[i];
-          const int px = static_cast<int>(p >> 16), py = static_cast<int>(p & 0xFFFFu);
-          if (px == row) atomicOr(&rowbits[py >> 5], 1u << (py & 31));
-          if (py == row) atomicOr(&rowbits[px >> 5], 1u << (px & 31));
-        }
+      const uint32_t* rowbits;
+      if (fast) {
+        rowbits = mat + row * wpr;
       } else {
+        for (int w = lane; w < wpr; w += 64) slowbits[w] = 0;
+        wave_sync();
         for (int i = lane; i < npairs; i += 64) {
           const uint2 p = pairs[i];
-          if (static_cast<int>(p.x) == row) atomicOr(&rowbits[p.y >> 5], 1u << (p.y & 31));
-          if (static_cast<int>(p.y) == row) atomicOr(&rowbits[p.x >> 5], 1u << (p.x & 31));
+          if (static_cast<int>(p.x) == row) atomicOr(&slowbits[p.y >> 5], 1u << (p.y & 31));
+          if (static_cast<int>(p.y) == row) atomicOr(&slowbits[p.x >> 5], 1u << (p.x & 31));
         }
+        wave_sync();
+        rowbits = slowbits;
       }
-      wave_sync();
-      const int pid = merge[row];
+      const int pid = fast ? lmerge[row] : merge[row];
       float pnx, pny, pnz, pd;
-      if (lds_view) {
+      if (fast) {
         const float* pv = pview + pid * 7;
         pnx = pv[0]; pny = pv[1]; pnz = pv[2]; pd = pv[3];
       } else {
@@ -474,7 +529,7 @@ __global__ __launch_bounds__(256) void k_regions2(Params prm, RegionBufs rb, Reg
         bool acc = false;
         if (col < nplanes && ((rowbits[col >> 5] >> (col & 31)) & 1u)) {
           float cnx, cny, cnz, cmx, cmy, cmz;
-          if (lds_view) {
+          if (fast) {
             const float* cv = pview + col * 7;
             cnx = cv[0]; cny = cv[1]; cnz = cv[2]; cmx = cv[4]; cmy = cv[5]; cmz = cv[6];
           } else {
@@ -495,7 +550,10 @@ __global__ __launch_bounds__(256) void k_regions2(Params prm, RegionBufs rb, Reg
           const float* cfp = reinterpret_cast<const float*>(&planes[colx]);
           if (lane < 9) pf[lane] = pf[lane] + cfp[lane];
           if (lane == 9) planes[pid].n_pts += planes[colx].n_pts;
-          if (lane == 10) merge[colx] = pid;
+          if (lane == 10) {
+            merge[colx] = pid;
+            if (fast) lmerge[colx] = pid;
+          }
           expanded = true;
           ++merges;
         }
@@ -510,7 +568,7 @@ __global__ __launch_bounds__(256) void k_regions2(Params prm, RegionBufs rb, Reg
           pl.mean[0] = fit.mean[0]; pl.mean[1] = fit.mean[1]; pl.mean[2] = fit.mean[2];
           pl.normal[0] = fit.normal[0]; pl.normal[1] = fit.normal[1]; pl.normal[2] = fit.normal[2];
           pl.d = fit.d; pl.mse = fit.mse; pl.score = fit.score;
-          if (lds_view) {
+          if (fast) {
             float* pv = pview + pid * 7;
             pv[0] = fit.normal[0]; pv[1] = fit.normal[1]; pv[2] = fit.normal[2]; pv[3] = fit.d;
             pv[4] = fit.mean[0]; pv[5] = fit.mean[1]; pv[6] = fit.mean[2];
@@ -524,14 +582,13 @@ __global__ __launch_bounds__(256) void k_regions2(Params prm, RegionBufs rb, Reg
   }
   __syncthreads();
   t_p5 = DPX_STAMP();
-  // ---------------- P6: merged label per cell; records -------------------------------------------------------
-  if (nplanes > 0) {
-    for (int c = tid; c < C; c += 256) {
-      const int L = cell_labels[c];
-      cell_labels[c] = L == 0 ? 0 : merge[L - 1] + 1;
-    }
-    for (int i = tid; i < nplanes; i += 256) planes[i].merge_label = merge[i];
+  // ---------------- P6: merged label per cell (toImageLabels' lookup, plane_extractor.cpp:464-465); records --------
+  for (int c = tid; c < C; c += kRT) {
+    const int L = lab16[c];
+    cell_labels[c] = (L == 0 || nplanes == 0) ? 0 : merge[L - 1] + 1;
   }
+  if (nplanes > 0)
+    for (int i = tid; i < nplanes; i += kRT) planes[i].merge_label = merge[i];
   if (tid == 0) {
     dpx_frame_stats st;
     st.planar_cells = planar_total;
