@@ -91,6 +91,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DPX_BENCH_STREAMS", 16)))
+    ap.add_argument("--region-streams", type=int, default=0, help="0: one stream per batch in flight (default); >0: staged mode")
+    ap.add_argument("--prof-every", type=int, default=8, help="record per-kernel HIP events on every n-th slot")
+    ap.add_argument("--roofline-iters", type=int, default=50)
+    ap.add_argument("--roofline-only", action="store_true", help="only the stand-alone plane-fit series (for rocprofv3 --stats / --pmc runs)")
     ap.add_argument("--workload", default="tum_stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-frames", type=int, default=4)
@@ -112,35 +116,57 @@ def main():
     N = H * W
     dev = torch.device("cuda", local_rank)
     d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
-    S = max(1, args.streams)
+    S = max(1, args.streams)  # batches in flight (pipeline slots), one stream each
     d_labels = torch.empty((S, B, N), dtype=torch.int32, device=dev)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
-    exs = [D.PlaneExtractor(H, W, D.Config(), max_batch=B, device=local_rank) for _ in range(S)]
+    pipe = D.Pipeline(H, W, D.Config(), batch=B, slots=S, region_streams=args.region_streams, device=local_rank)
+    exs = [pipe.slot(k) for k in range(S)]
     for ex in exs:
-        ex.set_profiling(True)
+        ex.prepare_intrinsics(*intr)  # one-time exact-division check, outside the timed region
+    # HIP events around every kernel of a slot cost ~35 % throughput when recorded on all slots (they serialise the
+    # queues); sample them on every `prof_every`-th slot instead
+    prof_slots = list(range(0, S, max(1, args.prof_every)))
+    for k in prof_slots:
+        exs[k].set_profiling(True)
 
     def step(i):
-        k = i % S
-        exs[k].process_depth_device(d_depth.data_ptr(), B, *intr, d_labels[k].data_ptr(), streams[k].cuda_stream)
+        pipe.submit_depth(d_depth.data_ptr(), B, *intr, d_labels[i % S].data_ptr())
 
     def sync():
+        pipe.sync()
         torch.cuda.synchronize(dev)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
+    if args.roofline_only:
+        rstream = torch.cuda.Stream(device=dev)
+        exs[0].time_planefit(d_depth.data_ptr(), 0, B, *intr, 5, rstream.cuda_stream)
+        ms = exs[0].time_planefit(d_depth.data_ptr(), 0, B, *intr, args.roofline_iters, rstream.cuda_stream)
+        by = exs[0].planefit_bytes(0, B)
+        print(json.dumps({"roofline_only": True, "kernel": "k_planefit_depth", "batch": B, "workload": args.workload,
+                          "avg_launch_ms": round(ms, 4), "bytes_per_launch": by,
+                          "achieved_GBps": round(by / (ms * 1e-3) / 1e9, 1), "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}))
+        return
     elapsed = timed_region(step, sync, barrier, args.steps, args.warmup)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-kernel durations measured with HIP events on the launch streams during the steps above
+    # per-kernel durations measured with HIP events on the launch streams during the timed steps (sampled slots).  With
+    # S batches in flight these include the time a launch spends sharing the GPU with the other batches' kernels.
     kms = {k: 0.0 for k in ("planefit", "cellgraph", "regions", "labels")}
-    for ex in exs[: min(S, args.steps + args.warmup)]:
-        for k, v in ex.kernel_ms().items():
-            kms[k] += v / min(S, args.steps + args.warmup)
+    used = [k for k in prof_slots if k < args.steps + args.warmup]
+    for k in used:
+        for name, v in exs[k].kernel_ms().items():
+            kms[name] += v / len(used)
+    # roofline of the plane-fit kernel: the same launch (same batch, same buffers) issued back to back on one stream
+    # right after the timed region, bracketed by HIP events on that stream
+    sync()
+    rstream = torch.cuda.Stream(device=dev)
+    exs[0].time_planefit(d_depth.data_ptr(), 0, B, *intr, 5, rstream.cuda_stream)
+    pf_alone_ms = exs[0].time_planefit(d_depth.data_ptr(), 0, B, *intr, args.roofline_iters, rstream.cuda_stream)
 
     # parity spot check against the oracle (outside the timed region; the oracle is only the checker)
     parity = "unchecked"
@@ -158,8 +184,9 @@ def main():
         total_frames = B * args.steps * world
         fps = total_frames / elapsed
         pf_bytes = exs[0].planefit_bytes(0, B)
-        pf_ms = kms["planefit"]
+        pf_ms = pf_alone_ms
         achieved = pf_bytes / (pf_ms * 1e-3) / 1e9 if pf_ms > 0 else 0.0
+        in_pipe = pf_bytes / (kms["planefit"] * 1e-3) / 1e9 if kms["planefit"] > 0 else 0.0
         traffic = None
         tfile = ROOT / "profiles" / "planefit_traffic.json"
         if tfile.exists():
@@ -174,7 +201,8 @@ def main():
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl_desc, "patch_size": 10, "batch_per_gpu": B, "streams": S,
+            "config": {"workload": wl_desc, "patch_size": 10, "batch_per_gpu": B, "batches_in_flight": S,
+                       "streams": f"{S} (one per batch in flight), GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}",
                        "arithmetic": "f32 moments (reference order), f64 3x3 eigen, int32 labels",
                        "parallelism": f"frame-shard x{world}, no collectives"},
             "parity": parity,
@@ -182,7 +210,10 @@ def main():
             "roofline": {"kernel": "k_planefit (depth -> per-cell moments + eigen plane fit)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "bytes_per_launch": pf_bytes, "avg_launch_ms": round(pf_ms, 4)},
+                         "bytes_per_launch": pf_bytes, "avg_launch_ms": round(pf_ms, 4),
+                         "measured": f"{args.roofline_iters} launches back to back on one stream after the timed region, HIP events on that stream",
+                         "in_pipeline": {"avg_launch_ms": round(kms["planefit"], 4), "achieved": round(in_pipe, 1),
+                                         "note": f"HIP events around the launches of the timed steps with {S} batches in flight (includes queueing behind / sharing with the other batches' kernels)"}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(depth, intr, min(16, os.cpu_count() or 1))  # the box's CPU share for one GPU

@@ -70,6 +70,11 @@ SYMBOLS = {
     "dpx_process_depth_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "dpx_process_depth_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "dpx_process_pcd_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "dpx_pipeline_create": (C.c_int, [C.POINTER(DpxConfig), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "dpx_pipeline_destroy": (None, [C.c_void_p]),
+    "dpx_pipeline_submit_depth": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "dpx_pipeline_sync": (C.c_int, [C.c_void_p]),
+    "dpx_pipeline_slot": (C.c_void_p, [C.c_void_p, C.c_int32]),
     "dpx_prepare_intrinsics": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_int32)]),
     "dpx_backproject": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int32]),
     "dpx_grid_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

@@ -78,7 +78,9 @@ struct dpx_handle_s {
   // profiling: a ring of event sets, one per process call
   bool profiling = false;
   static constexpr int kProfSlots = 128;
-  hipEvent_t ev[kProfSlots][DPX_K_COUNT + 1] = {};
+  hipEvent_t ev[kProfSlots][7] = {};  // fit start/end, graph start, graph end = regions start, regions end, labels start/end
+  hipEvent_t ev_sync[3] = {};          // stage hand-off events for multi-stream pipelines
+  bool sync_recorded = false;
   bool ev_created = false;
   long long prof_calls = 0;
   int last_batch = 0;
@@ -117,6 +119,8 @@ void free_all(dpx_handle h) {
   for (auto& slot : h->ev)
     for (auto& e : slot)
       if (e) hipEventDestroy(e);
+  for (auto& e : h->ev_sync)
+    if (e) hipEventDestroy(e);
   if (h->stream) hipStreamDestroy(h->stream);
 }
 
@@ -192,35 +196,50 @@ void launch_planefit_depth(dpx_handle h, const dpx::Params& prm, const void* d_i
   launch_planefit<true>(prm, d_in, h->d_cells, s);
 }
 
-int run_pipeline(dpx_handle h, const void* d_in, bool depth, int batch, float fx, float fy, float cx, float cy,
-                 int32_t* d_labels, hipStream_t s) {
+// One batch through the three stages.  With a single stream the stages are ordered by the stream; with distinct
+// streams (dpx_pipeline) the handle's events order them: plane fit on s_fit, region growing on s_reg, label expansion
+// on s_lab, and the next use of this handle's scratch waits for the previous label expansion.
+int run_pipeline3(dpx_handle h, const void* d_in, bool depth, int batch, float fx, float fy, float cx, float cy,
+                  int32_t* d_labels, hipStream_t s_fit, hipStream_t s_reg, hipStream_t s_lab) {
   if (batch < 0 || batch > h->max_batch)
     return fail(DPX_ERR_ARG, "batch " + std::to_string(batch) + " exceeds max_batch " + std::to_string(h->max_batch));
   DPX_HIP(hipSetDevice(h->device));
-  h->last_stream = s;
+  h->last_stream = s_lab;
   h->last_batch = batch;
   if (batch == 0) return DPX_OK;
   if (depth) {
     const int rcp = prepare_intrinsics(h, fx, fy, cx, cy);
     if (rcp) return rcp;
   }
+  const bool multi = (s_fit != s_reg) || (s_reg != s_lab);
+  if (multi && !h->ev_sync[0]) {
+    for (auto& e : h->ev_sync) DPX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
   dpx::Params prm = h->prm;
   prm.batch = batch;
   prm.fx = fx; prm.fy = fy; prm.cx = cx; prm.cy = cy;
   const bool prof = h->profiling;
   hipEvent_t* ev = h->ev[h->prof_calls % dpx_handle_s::kProfSlots];
-  if (prof) DPX_HIP(hipEventRecord(ev[0], s));
+  if (multi && h->sync_recorded) DPX_HIP(hipStreamWaitEvent(s_fit, h->ev_sync[2], 0));
+  // ---- stage 1: plane fit
+  if (prof) DPX_HIP(hipEventRecord(ev[0], s_fit));
   if (prm.C > 0) {
     if (depth)
-      launch_planefit_depth(h, prm, d_in, s);
+      launch_planefit_depth(h, prm, d_in, s_fit);
     else
-      launch_planefit<false>(prm, d_in, h->d_cells, s);
+      launch_planefit<false>(prm, d_in, h->d_cells, s_fit);
   }
-  if (prof) DPX_HIP(hipEventRecord(ev[1], s));
+  if (prof) DPX_HIP(hipEventRecord(ev[1], s_fit));
+  if (multi) {
+    DPX_HIP(hipEventRecord(h->ev_sync[0], s_fit));
+    DPX_HIP(hipStreamWaitEvent(s_reg, h->ev_sync[0], 0));
+  }
+  // ---- stage 2: cell graph (only when the region kernel does not compute it itself) + region growing
+  if (prof) DPX_HIP(hipEventRecord(ev[2], s_reg));
   const long long total = static_cast<long long>(batch) * prm.C;
-  if (total > 0 && h->regions_tier != 2)  // the FULL-tier region kernel computes the cell graph itself
-    hipLaunchKernelGGL(dpx::k_cellgraph, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, prm, h->d_cells, h->d_meta, h->d_mse_c);
-  if (prof) DPX_HIP(hipEventRecord(ev[2], s));
+  if (total > 0 && h->regions_tier != 2)
+    hipLaunchKernelGGL(dpx::k_cellgraph, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s_reg, prm, h->d_cells, h->d_meta, h->d_mse_c);
+  if (prof) DPX_HIP(hipEventRecord(ev[3], s_reg));
   dpx::RegionBufs rb{};
   rb.cells = h->d_cells; rb.meta = h->d_meta; rb.order = h->d_order; rb.grow_start = h->d_grow_start;
   rb.cand = h->d_cand; rb.planes = h->d_planes; rb.cell_labels = h->d_cell_labels; rb.pairs = h->d_pairs;
@@ -228,28 +247,43 @@ int run_pipeline(dpx_handle h, const void* d_in, bool depth, int batch, float fx
   rb.g_queue = h->d_gqueue; rb.pcap = h->pcap;
   dpx::Regions2Extra rx{h->d_mse_c, h->d_cand_grow, h->d_dbg};
   if (h->regions_tier == 2 && h->d_dbg)
-    hipLaunchKernelGGL((dpx::k_regions2<true, true>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<true, true>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s_reg, prm, rb, rx);
   else if (h->regions_tier == 2)
-    hipLaunchKernelGGL((dpx::k_regions2<true, false>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<true, false>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s_reg, prm, rb, rx);
   else if (h->regions_tier == 1)
-    hipLaunchKernelGGL((dpx::k_regions2<false, false>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<false, false>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s_reg, prm, rb, rx);
   else if (h->use_lds)
-    hipLaunchKernelGGL(dpx::k_regions<true>, dim3(batch), dim3(64), h->lds_bytes, s, prm, rb);
+    hipLaunchKernelGGL(dpx::k_regions<true>, dim3(batch), dim3(64), h->lds_bytes, s_reg, prm, rb);
   else
-    hipLaunchKernelGGL(dpx::k_regions<false>, dim3(batch), dim3(64), h->lds_bytes, s, prm, rb);
-  if (prof) DPX_HIP(hipEventRecord(ev[3], s));
+    hipLaunchKernelGGL(dpx::k_regions<false>, dim3(batch), dim3(64), h->lds_bytes, s_reg, prm, rb);
+  if (prof) DPX_HIP(hipEventRecord(ev[4], s_reg));
+  if (multi) {
+    DPX_HIP(hipEventRecord(h->ev_sync[1], s_reg));
+    DPX_HIP(hipStreamWaitEvent(s_lab, h->ev_sync[1], 0));
+  }
+  // ---- stage 3: label expansion
+  if (prof) DPX_HIP(hipEventRecord(ev[5], s_lab));
   {
     const long long per_frame = static_cast<long long>(prm.H) * ((prm.W + 3) / 4);
     const long long tot = per_frame * batch;
     if (tot > 0)
-      hipLaunchKernelGGL(dpx::k_labels, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s, prm, h->d_cell_labels, d_labels);
+      hipLaunchKernelGGL(dpx::k_labels, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s_lab, prm, h->d_cell_labels, d_labels);
   }
   if (prof) {
-    DPX_HIP(hipEventRecord(ev[4], s));
+    DPX_HIP(hipEventRecord(ev[6], s_lab));
     ++h->prof_calls;
+  }
+  if (multi) {
+    DPX_HIP(hipEventRecord(h->ev_sync[2], s_lab));
+    h->sync_recorded = true;
   }
   DPX_HIP(hipGetLastError());
   return DPX_OK;
+}
+
+int run_pipeline(dpx_handle h, const void* d_in, bool depth, int batch, float fx, float fy, float cx, float cy,
+                 int32_t* d_labels, hipStream_t s) {
+  return run_pipeline3(h, d_in, depth, batch, fx, fy, cx, cy, d_labels, s, s, s);
 }
 
 int ensure_staging(dpx_handle h, size_t in_bytes, size_t label_bytes) {
@@ -680,6 +714,91 @@ int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_
   return DPX_OK;
 }
 
+// ---- multi-stream pipeline: `depth` batches in flight, stages on dedicated streams -------------------------------
+struct dpx_pipeline_s {
+  std::vector<dpx_handle> slots;
+  std::vector<hipStream_t> s_reg;
+  hipStream_t s_fit = nullptr, s_lab = nullptr;
+  long long submitted = 0;
+  int device = 0;
+};
+
+int dpx_pipeline_create(const dpx_config* cfg, int32_t image_height, int32_t image_width, int32_t batch, int32_t device,
+                        int32_t slots, int32_t region_streams, dpx_pipeline* out) {
+  if (!out || slots < 1 || region_streams < 0) return fail(DPX_ERR_ARG, "bad pipeline arguments");
+  *out = nullptr;
+  dpx_pipeline p = new dpx_pipeline_s();
+  p->device = device;
+  for (int i = 0; i < slots; ++i) {
+    dpx_handle h = nullptr;
+    const int rc = dpx_create(cfg, image_height, image_width, batch, device, &h);
+    if (rc != DPX_OK) {
+      const std::string keep = g_err;
+      dpx_pipeline_destroy(p);
+      g_err = keep;
+      return rc;
+    }
+    p->slots.push_back(h);
+  }
+  // region_streams == 0 (default mode): every slot runs its three kernels on its own stream, no cross-stream events
+  // (hand-offs between streams cost ~20-30 us each on this stack, measured with tools/host_overhead.py);
+  // region_streams > 0: staged mode, plane fits / label expansions each serialised on one stream.
+  bool ok = true;
+  if (region_streams > 0)
+    ok = hipStreamCreateWithFlags(&p->s_fit, hipStreamNonBlocking) == hipSuccess &&
+         hipStreamCreateWithFlags(&p->s_lab, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; ok && i < region_streams; ++i) {
+    hipStream_t s = nullptr;
+    ok = hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;
+    if (ok) p->s_reg.push_back(s);
+  }
+  if (!ok) {
+    dpx_pipeline_destroy(p);
+    return fail(DPX_ERR_HIP, "hipStreamCreate failed");
+  }
+  *out = p;
+  return DPX_OK;
+}
+
+void dpx_pipeline_destroy(dpx_pipeline p) {
+  if (!p) return;
+  (void)hipSetDevice(p->device);
+  (void)hipDeviceSynchronize();
+  for (auto h : p->slots) dpx_destroy(h);
+  if (p->s_fit) hipStreamDestroy(p->s_fit);
+  if (p->s_lab) hipStreamDestroy(p->s_lab);
+  for (auto s : p->s_reg) hipStreamDestroy(s);
+  delete p;
+}
+
+int dpx_pipeline_submit_depth(dpx_pipeline p, const void* d_depth, int32_t batch, float fx, float fy, float cx, float cy,
+                              void* d_labels) {
+  if (!p || (batch > 0 && (!d_depth || !d_labels))) return fail(DPX_ERR_ARG, "bad argument");
+  const long long n = p->submitted++;
+  dpx_handle h = p->slots[n % p->slots.size()];
+  if (p->s_reg.empty()) return run_pipeline(h, d_depth, true, batch, fx, fy, cx, cy, static_cast<int32_t*>(d_labels), h->stream);
+  return run_pipeline3(h, d_depth, true, batch, fx, fy, cx, cy, static_cast<int32_t*>(d_labels), p->s_fit,
+                       p->s_reg[n % p->s_reg.size()], p->s_lab);
+}
+
+int dpx_pipeline_sync(dpx_pipeline p) {
+  if (!p) return fail(DPX_ERR_ARG, "null pipeline");
+  DPX_HIP(hipSetDevice(p->device));
+  if (p->s_reg.empty()) {
+    for (auto h : p->slots) DPX_HIP(hipStreamSynchronize(h->stream));
+    return DPX_OK;
+  }
+  DPX_HIP(hipStreamSynchronize(p->s_fit));
+  for (auto s : p->s_reg) DPX_HIP(hipStreamSynchronize(s));
+  DPX_HIP(hipStreamSynchronize(p->s_lab));
+  return DPX_OK;
+}
+
+dpx_handle dpx_pipeline_slot(dpx_pipeline p, int32_t slot) {
+  if (!p || slot < 0 || slot >= static_cast<int>(p->slots.size())) return nullptr;
+  return p->slots[slot];
+}
+
 int dpx_set_profiling(dpx_handle h, int32_t enable) {
   if (!h) return fail(DPX_ERR_ARG, "null handle");
   DPX_HIP(hipSetDevice(h->device));
@@ -699,11 +818,12 @@ int dpx_get_kernel_ms(dpx_handle h, float* ms) {
   DPX_HIP(hipSetDevice(h->device));
   const int n = static_cast<int>(std::min<long long>(h->prof_calls, dpx_handle_s::kProfSlots));
   double acc[DPX_K_COUNT] = {};
+  static const int kStart[DPX_K_COUNT] = {0, 2, 3, 5}, kEnd[DPX_K_COUNT] = {1, 3, 4, 6};
   for (int i = 0; i < n; ++i) {
-    DPX_HIP(hipEventSynchronize(h->ev[i][DPX_K_COUNT]));
+    DPX_HIP(hipEventSynchronize(h->ev[i][6]));
     for (int k = 0; k < DPX_K_COUNT; ++k) {
       float t = 0.f;
-      DPX_HIP(hipEventElapsedTime(&t, h->ev[i][k], h->ev[i][k + 1]));
+      DPX_HIP(hipEventElapsedTime(&t, h->ev[i][kStart[k]], h->ev[i][kEnd[k]]));
       acc[k] += t;
     }
   }

@@ -77,6 +77,8 @@ class PlaneExtractor:
 
     def __del__(self):
         h = getattr(self, "_h", None)
+        if getattr(self, "_borrowed", False):
+            return
         if h is not None and h.value:
             try:
                 _capi.lib().dpx_destroy(h)
@@ -184,3 +186,46 @@ class PlaneExtractor:
 
     def planefit_bytes(self, input_kind: int, batch: int) -> int:
         return int(_capi.lib().dpx_planefit_bytes(self._h, input_kind, batch))
+
+
+class Pipeline:
+    """Streamed, pipelined processing of depth batches that already live in device memory (dpx_pipeline_*):
+    `slots` batches in flight, one stream per slot (region_streams=0) so the latency-bound region growing of one batch
+    overlaps the other batches' plane fits and label expansions; region_streams>0 selects the staged mode."""
+
+    def __init__(self, image_height: int, image_width: int, config: Optional[Config] = None, *, batch: int = 64,
+                 slots: int = 16, region_streams: int = 0, device: int = 0):
+        self._p = C.c_void_p()
+        cfg = config if config is not None else Config()
+        self.image_height, self.image_width, self.batch, self.slots = int(image_height), int(image_width), int(batch), int(slots)
+        _capi.check(_capi.lib().dpx_pipeline_create(C.byref(cfg._c), self.image_height, self.image_width, self.batch,
+                                                   int(device), self.slots, int(region_streams), C.byref(self._p)))
+
+    def submit_depth(self, d_depth_ptr: int, batch: int, fx, fy, cx, cy, d_labels_ptr: int) -> None:
+        _capi.check(_capi.lib().dpx_pipeline_submit_depth(self._p, d_depth_ptr, batch, fx, fy, cx, cy, d_labels_ptr))
+
+    def sync(self) -> None:
+        _capi.check(_capi.lib().dpx_pipeline_sync(self._p))
+
+    def slot(self, k: int) -> "PlaneExtractor":
+        """A non-owning PlaneExtractor view of slot k (result getters, profiling)."""
+        h = _capi.lib().dpx_pipeline_slot(self._p, k)
+        if not h:
+            raise IndexError(k)
+        ex = PlaneExtractor.__new__(PlaneExtractor)
+        ex._h = C.c_void_p(h)
+        ex.image_height, ex.image_width, ex.max_batch = self.image_height, self.image_width, self.batch
+        nh, nv = C.c_int32(), C.c_int32()
+        _capi.check(_capi.lib().dpx_grid_dims(ex._h, C.byref(nh), C.byref(nv)))
+        ex.nh, ex.nv = nh.value, nv.value
+        ex._borrowed = True
+        return ex
+
+    def __del__(self):
+        p = getattr(self, "_p", None)
+        if p is not None and p.value:
+            try:
+                _capi.lib().dpx_pipeline_destroy(p)
+            except Exception:
+                pass
+            self._p = C.c_void_p()

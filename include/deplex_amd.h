@@ -74,6 +74,7 @@ typedef struct dpx_frame_stats {
 } dpx_frame_stats;
 
 typedef struct dpx_handle_s* dpx_handle;
+typedef struct dpx_pipeline_s* dpx_pipeline;
 
 enum {
   DPX_OK = 0,
@@ -130,6 +131,22 @@ int dpx_process_depth_batch(dpx_handle h, const uint16_t* depth, int32_t batch, 
 int dpx_process_depth_batch_device(dpx_handle h, const void* d_depth, int32_t batch, float fx, float fy, float cx,
                                    float cy, void* d_labels, void* hip_stream);
 int dpx_process_pcd_batch_device(dpx_handle h, const void* d_xyz, int32_t batch, void* d_labels, void* hip_stream);
+
+/* Streamed processing (the reference's examples/process_sequence.cpp:30-53 loop, pipelined): `slots` batches in
+ * flight, each with its own scratch and — with region_streams == 0, the default mode — its own stream, so the
+ * latency-bound region growing of one batch overlaps the plane fits and label expansions of the others.
+ * region_streams > 0 selects a staged mode (plane fits serialised on one stream, label expansions on another, region
+ * growing on `region_streams` streams, hand-offs through events); it is slower on ROCm 7.2 and kept for comparison.
+ * submit() is asynchronous on device pointers; the caller must not reuse d_depth / d_labels of a submission before
+ * dpx_pipeline_sync() (or `slots` later submissions) completed.  dpx_pipeline_slot() exposes the per-slot handle
+ * for the result getters and profiling. */
+int dpx_pipeline_create(const dpx_config* cfg, int32_t image_height, int32_t image_width, int32_t batch, int32_t device,
+                        int32_t slots, int32_t region_streams, dpx_pipeline* out);
+void dpx_pipeline_destroy(dpx_pipeline p);
+int dpx_pipeline_submit_depth(dpx_pipeline p, const void* d_depth, int32_t batch, float fx, float fy, float cx, float cy,
+                              void* d_labels);
+int dpx_pipeline_sync(dpx_pipeline p);
+dpx_handle dpx_pipeline_slot(dpx_pipeline p, int32_t slot);
 
 /* Optional: validate intrinsics ahead of the first depth call (the fused kernel divides by fx, fy through a
  * reciprocal sequence that is checked exhaustively against IEEE division for this image geometry; the check

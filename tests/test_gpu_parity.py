@@ -317,3 +317,33 @@ def test_device_pointer_api_with_torch(D, oracle):
     assert all(v >= 0 for v in ms.values()) and ms["planefit"] > 0
     t = ex.time_planefit(d_depth.data_ptr(), 0, 3, *intr, 5, stream.cuda_stream)
     assert t > 0 and ex.planefit_bytes(0, 3) == 3 * (240 * 320 * 2 + 32 * 24 * 64)
+
+
+def test_multistream_pipeline(D, oracle):
+    """dpx_pipeline: several batches in flight on separate plane-fit / region / label streams give the same bits as
+    the single-stream path, including when scratch slots are reused."""
+    import torch
+    h, w, B, steps = 240, 320, 4, 7
+    intr = synth.intrinsics_for(h, w)
+    dev = torch.device("cuda", 0)
+    batches = [synth.synth_batch(B, h, w, seed0=100 + 10 * i) for i in range(steps)]
+    d_in = [torch.from_numpy(b.view(np.int16)).to(dev) for b in batches]
+    d_out = [torch.full((B, h * w), -1, dtype=torch.int32, device=dev) for _ in range(steps)]
+    oracle.set_math("devmath")
+    refs = [oracle.process_depth_batch(oracle.default_config(), b, *intr, threads=2) for b in batches]
+    for region_streams in (0, 2):  # per-slot streams (default) and the staged mode
+        for o in d_out:
+            o.fill_(-1)
+        pipe = D.Pipeline(h, w, D.Config(), batch=B, slots=3, region_streams=region_streams)
+        for k in range(3):
+            pipe.slot(k).set_profiling(True)
+        torch.cuda.synchronize()
+        for i in range(steps):
+            pipe.submit_depth(d_in[i].data_ptr(), B, *intr, d_out[i].data_ptr())
+        pipe.sync()
+        for i in range(steps):
+            assert np.array_equal(d_out[i].cpu().numpy(), refs[i]), f"mode {region_streams} batch {i}"
+        ms = pipe.slot(0).kernel_ms()
+        assert ms["planefit"] > 0 and ms["regions"] > 0 and ms["labels"] > 0
+        assert pipe.slot((steps - 1) % 3).frame_stats(0)["segments"] >= 0
+        del pipe
