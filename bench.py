@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--region-streams", type=int, default=0, help="0: one stream per batch in flight (default); >0: staged mode")
     ap.add_argument("--prof-every", type=int, default=8, help="record per-kernel HIP events on every n-th slot")
     ap.add_argument("--roofline-iters", type=int, default=50)
+    ap.add_argument("--no-cloud-roofline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="only the stand-alone plane-fit series (for rocprofv3 --stats / --pmc runs)")
     ap.add_argument("--workload", default="tum_stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -167,6 +168,15 @@ def main():
     rstream = torch.cuda.Stream(device=dev)
     exs[0].time_planefit(d_depth.data_ptr(), 0, B, *intr, 5, rstream.cuda_stream)
     pf_alone_ms = exs[0].time_planefit(d_depth.data_ptr(), 0, B, *intr, args.roofline_iters, rstream.cuda_stream)
+    # the same kernel stage fed with the reference API's own input (organised float32 cloud, 12 B/point)
+    cloud_ms = None
+    if rank == 0 and not args.no_cloud_roofline:
+        from oracle import oracle as O  # back-projection of the bench frames (outside any timed region)
+        xyz = np.stack([O.backproject(f, *[np.float32(v) for v in intr]) for f in depth])
+        d_xyz = torch.from_numpy(xyz).to(dev)
+        exs[0].time_planefit(d_xyz.data_ptr(), 1, B, *intr, 5, rstream.cuda_stream)
+        cloud_ms = exs[0].time_planefit(d_xyz.data_ptr(), 1, B, *intr, args.roofline_iters, rstream.cuda_stream)
+        del d_xyz
 
     # parity spot check against the oracle (outside the timed region; the oracle is only the checker)
     parity = "unchecked"
@@ -215,6 +225,12 @@ def main():
                          "in_pipeline": {"avg_launch_ms": round(kms["planefit"], 4), "achieved": round(in_pipe, 1),
                                          "note": f"HIP events around the launches of the timed steps with {S} batches in flight (includes queueing behind / sharing with the other batches' kernels)"}},
         }
+        if cloud_ms:
+            cb = exs[0].planefit_bytes(1, B)
+            out["roofline_cloud_input"] = {"kernel": "k_planefit_cloud (organised xyz cloud -> per-cell moments + eigen plane fit)",
+                                           "bound": "hbm", "achieved": round(cb / (cloud_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                           "unit": "GB/s", "frac": round(cb / (cloud_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                           "bytes_per_launch": cb, "avg_launch_ms": round(cloud_ms, 4)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(depth, intr, min(16, os.cpu_count() or 1))  # the box's CPU share for one GPU
         print(json.dumps(out), flush=True)

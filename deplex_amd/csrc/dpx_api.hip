@@ -183,6 +183,22 @@ void launch_planefit(const dpx::Params& prm, const void* d_in, dpx_cell* d_cells
   }
 }
 
+void launch_planefit_cloud(dpx_handle h, const dpx::Params& prm, const void* d_in, hipStream_t s) {
+  const char* v1 = std::getenv("DPX_PLANEFIT_V1");
+  if (fast_shape(prm) && !(v1 && v1[0] == '1')) {
+    const long long waves = static_cast<long long>(prm.batch) * prm.nv * ((prm.nh + 63) / 64);
+    const unsigned blocks = static_cast<unsigned>((waves + 3) / 4);
+    const float* xyz = static_cast<const float*>(d_in);
+    switch (prm.P) {
+      case 4: hipLaunchKernelGGL((dpx::k_planefit_cloud<4>), dim3(blocks), dim3(256), 0, s, prm, xyz, h->d_cells); return;
+      case 8: hipLaunchKernelGGL((dpx::k_planefit_cloud<8>), dim3(blocks), dim3(256), 0, s, prm, xyz, h->d_cells); return;
+      case 10: hipLaunchKernelGGL((dpx::k_planefit_cloud<10>), dim3(blocks), dim3(256), 0, s, prm, xyz, h->d_cells); return;
+      default: break;
+    }
+  }
+  launch_planefit<false>(prm, d_in, h->d_cells, s);
+}
+
 void launch_planefit_depth(dpx_handle h, const dpx::Params& prm, const void* d_in, hipStream_t s) {
   const char* v1 = std::getenv("DPX_PLANEFIT_V1");
   if (fast_shape(prm) && !(v1 && v1[0] == '1')) {
@@ -227,7 +243,7 @@ int run_pipeline3(dpx_handle h, const void* d_in, bool depth, int batch, float f
     if (depth)
       launch_planefit_depth(h, prm, d_in, s_fit);
     else
-      launch_planefit<false>(prm, d_in, h->d_cells, s_fit);
+      launch_planefit_cloud(h, prm, d_in, s_fit);
   }
   if (prof) DPX_HIP(hipEventRecord(ev[1], s_fit));
   if (multi) {
@@ -852,7 +868,7 @@ int dpx_time_planefit(dpx_handle h, const void* d_in, int32_t input_kind, int32_
     if (input_kind == 0)
       launch_planefit_depth(h, prm, d_in, s);
     else
-      launch_planefit<false>(prm, d_in, h->d_cells, s);
+      launch_planefit_cloud(h, prm, d_in, s);
   }
   DPX_HIP(hipEventRecord(b, s));
   DPX_HIP(hipEventSynchronize(b));

@@ -104,6 +104,12 @@ struct CellAcc {
     const float x = div_const<FASTDIV>(cx_j * z, prm.fx, rx);
     const float y = div_const<FASTDIV>(cy_i * z, prm.fy, ry);
     valid_pts += zi != 0u;
+    point<J, KM, TAIL, TAILIDX, FIRST, LAST, HROW>(x, y, z, prm);
+  }
+
+  // One point of the organised cloud (also the tail of pixel()): continuity scans, moments.
+  template <int J, int KM, bool TAIL, int TAILIDX, bool FIRST, bool LAST, bool HROW>
+  __device__ __forceinline__ void point(float x, float y, float z, const Params& prm) {
     if (FIRST) { fx0 = x; fy0 = y; fz0 = z; }
     if (LAST) { lx = x; ly = y; lz = z; }
     if (HROW) {  // centre row, in j order (cell_segment.cpp:62-76)
@@ -165,12 +171,37 @@ struct CellAcc {
     // the work into phases (all converts/products first, the sequential chain adds last) and spills hundreds of
     // values.  The empty asm pins every accumulator touched by the last DPX_PF_GROUP pixels at this point of the
     // instruction stream; inside a group the scheduler is free to interleave the pixels' independent work (ILP).
-    if ((J % DPX_PF_GROUP) == DPX_PF_GROUP - 1 || J == P - 1) {
+    if ((J % DPX_PF_GROUP) == DPX_PF_GROUP - 1 || J == P - 1) pin();
+  }
+
+  __device__ __forceinline__ void pin() {
+    {
       asm volatile("" : "+v"(sx.c[0]), "+v"(sx.c[1]), "+v"(sx.c[2]), "+v"(sx.c[3]), "+v"(sx.c[4]), "+v"(sx.c[5]), "+v"(sx.c[6]), "+v"(sx.c[7]));
       asm volatile("" : "+v"(sy.c[0]), "+v"(sy.c[1]), "+v"(sy.c[2]), "+v"(sy.c[3]), "+v"(sy.c[4]), "+v"(sy.c[5]), "+v"(sy.c[6]), "+v"(sy.c[7]));
       asm volatile("" : "+v"(sz.c[0]), "+v"(sz.c[1]), "+v"(sz.c[2]), "+v"(sz.c[3]), "+v"(sz.c[4]), "+v"(sz.c[5]), "+v"(sz.c[6]), "+v"(sz.c[7]));
       asm volatile("" : "+v"(xx), "+v"(xy), "+v"(xz), "+v"(yy), "+v"(yz), "+v"(zz));
     }
+  }
+
+  // ---- organised-cloud input: row i of the cell is 3*P floats (x y z per point), all indices static
+  template <int I>
+  __device__ __forceinline__ void cloud_row(const float (&w)[3 * P], const Params& prm) {
+    cloud_row_impl<I>(w, prm, std::make_integer_sequence<int, P>{});
+  }
+  template <int I, int... Js>
+  __device__ __forceinline__ void cloud_row_impl(const float (&w)[3 * P], const Params& prm, std::integer_sequence<int, Js...>) {
+    (cloud_one<I, Js>(w, prm), ...);
+  }
+  template <int I, int J>
+  __device__ __forceinline__ void cloud_one(const float (&w)[3 * P], const Params& prm) {
+    constexpr int K = I * P + J;
+    constexpr int KM = K & 7;
+    constexpr bool TAIL = K >= A2;
+    constexpr int TAILIDX = TAIL ? K - A2 : 0;
+    const float x = w[3 * J], y = w[3 * J + 1], z = w[3 * J + 2];
+    valid_pts += z > 0;
+    point<J, KM, TAIL, TAILIDX, K == 0, K == n - 1, I == P / 2>(x, y, z, prm);
+    if ((J % DPX_PF_GROUP) == DPX_PF_GROUP - 1 || J == P - 1) pin();
   }
 };
 
@@ -330,6 +361,99 @@ __global__ __launch_bounds__(256, DPX_PF_WAVES) void k_planefit_depth(Params prm
     rec.pp[0] = pp[0]; rec.pp[1] = pp[1]; rec.pp[2] = pp[2]; rec.pp[3] = pp[3]; rec.pp[4] = pp[4]; rec.pp[5] = pp[5];
     rec.normal[0] = acc.fx0 - acc.lx; rec.normal[1] = acc.fy0 - acc.ly; rec.normal[2] = acc.fz0 - acc.lz;
     rec.d = 0.f; rec.mse = 0.f; rec.tol = 0.f; rec.info = valid ? 1u : 0u;
+  }
+  float4* dst = reinterpret_cast<float4*>(cells + static_cast<long long>(frame) * prm.C + static_cast<long long>(cr) * prm.nh + cc);
+  const float4* s4 = reinterpret_cast<const float4*>(&rec);
+  dst[0] = s4[0];
+  dst[1] = s4[1];
+  dst[2] = s4[2];
+  dst[3] = s4[3];
+}
+
+// ---- organised-cloud input (the reference API's own input, plane_extractor.h:48): 12 B/point, no back-projection --
+// Same lane = cell mapping; a cell row is 3*P contiguous floats.  One row is in flight behind the row being
+// processed (120 B per lane for P = 10).  Memory-bound: 17 VALU ops per 12 input bytes.
+template <int P>
+__device__ __forceinline__ void load_cloud_row(const float* rowp, float (&w)[3 * P]) {
+  constexpr int DWR = 3 * P;
+  const uint32_t* rp = reinterpret_cast<const uint32_t*>(rowp);
+  int d = 0;
+#pragma unroll
+  for (; d + 4 <= DWR; d += 4) {
+    const u32x4a v = *reinterpret_cast<const u32x4a*>(rp + d);
+    w[d] = __uint_as_float(v.x); w[d + 1] = __uint_as_float(v.y); w[d + 2] = __uint_as_float(v.z); w[d + 3] = __uint_as_float(v.w);
+  }
+  if (d + 2 <= DWR) {
+    const u32x2a v = *reinterpret_cast<const u32x2a*>(rp + d);
+    w[d] = __uint_as_float(v.x); w[d + 1] = __uint_as_float(v.y);
+    d += 2;
+  }
+  if (d < DWR) w[d] = __uint_as_float(rp[d]);
+}
+
+template <int P, int I>
+struct CloudRows {
+  template <class ACC>
+  static __device__ __forceinline__ void run(ACC& acc, const float* src, long long row_stride, float (&a)[3 * P], float (&b)[3 * P],
+                                             const Params& prm) {
+    // row I is in `a`; fetch row I+1 into `b`, process row I, then continue with the roles swapped
+    if (I + 1 < P) load_cloud_row<P>(src + static_cast<long long>(I + 1) * row_stride, b);
+    if (I == 0) acc.vprev = a[3 * (P / 2) + 2];  // k = P/2 -> (i = 0, j = P/2)
+    acc.template cloud_row<I>(a, prm);
+    asm volatile("" ::: "memory");  // keep the next row's loads where they are (one row ahead, not all at the top)
+    if (I + 1 < P) CloudRows<P, (I + 1 < P ? I + 1 : P)>::run(acc, src, row_stride, b, a, prm);
+  }
+};
+template <int P>
+struct CloudRows<P, P> {
+  template <class ACC>
+  static __device__ __forceinline__ void run(ACC&, const float*, long long, float (&)[3 * P], float (&)[3 * P], const Params&) {}
+};
+
+template <int P>
+__global__ __launch_bounds__(256, 3) void k_planefit_cloud(Params prm, const float* __restrict__ xyz,
+                                                                       dpx_cell* __restrict__ cells) {
+  static_assert(P % 2 == 0 && P >= 2, "even patch sizes only");
+  constexpr int n = P * P;
+  constexpr int A2 = (n / 8) * 8;
+  const int strips = (prm.nh + 63) >> 6;
+  const long long wave = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const long long per_frame = static_cast<long long>(prm.nv) * strips;
+  if (wave >= per_frame * prm.batch) return;
+  const int frame = static_cast<int>(wave / per_frame);
+  const int rem = static_cast<int>(wave - frame * per_frame);
+  const int cr = rem / strips;
+  const int cc = (rem - cr * strips) * 64 + lane;
+  if (cc >= prm.nh) return;
+  const long long row_stride = 3ll * prm.W;
+  const float* src = xyz + 3ll * (static_cast<long long>(frame) * prm.N + static_cast<long long>(cr) * P * prm.W + static_cast<long long>(cc) * P);
+
+  CellAcc<P, false> acc;
+  acc.init();
+  float a[3 * P], b[3 * P];
+  load_cloud_row<P>(src, a);
+  CloudRows<P, 0>::run(acc, src, row_stride, a, b, prm);
+
+  if (A2 > 0 && n == A2) { acc.sx.fold(); acc.sy.fold(); acc.sz.fold(); }
+  float sum[3], pp[6];
+  sum[0] = (acc.sx.c[0] + acc.sx.c[2]) + (acc.sx.c[1] + acc.sx.c[3]);
+  sum[1] = (acc.sy.c[0] + acc.sy.c[2]) + (acc.sy.c[1] + acc.sy.c[3]);
+  sum[2] = (acc.sz.c[0] + acc.sz.c[2]) + (acc.sz.c[1] + acc.sz.c[3]);
+  pp[0] = acc.xx; pp[1] = acc.xy; pp[2] = acc.xz; pp[3] = acc.yy; pp[4] = acc.yz; pp[5] = acc.zz;
+  const bool cont = (acc.hdisc < prm.max_disc) && (acc.vdisc < prm.max_disc);
+  const bool valid = prm.valid_thr >= 0 && static_cast<long long>(acc.valid_pts) >= prm.valid_thr && cont;
+  dpx_cell rec;
+  if (valid) {
+    finish_cell(prm, n, sum, pp, acc.fx0 - acc.lx, acc.fy0 - acc.ly, acc.fz0 - acc.lz, true, rec);
+  } else {
+    rec.sum[0] = rec.sum[1] = rec.sum[2] = 0.f;
+    rec.pp[0] = rec.pp[1] = rec.pp[2] = rec.pp[3] = rec.pp[4] = rec.pp[5] = 0.f;
+    rec.normal[0] = rec.normal[1] = rec.normal[2] = 0.f;
+    rec.d = 0.f;
+    rec.mse = 3.402823466e+38f;
+    rec.tol = 0.f;
+    rec.info = 0u;
   }
   float4* dst = reinterpret_cast<float4*>(cells + static_cast<long long>(frame) * prm.C + static_cast<long long>(cr) * prm.nh + cc);
   const float4* s4 = reinterpret_cast<const float4*>(&rec);

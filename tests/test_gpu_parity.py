@@ -165,6 +165,29 @@ def test_patch_sizes(D, oracle, patch):
     full_compare(D, oracle, depth, synth.intrinsics_for(240, 320), oracle.default_config(patch_size=patch))
 
 
+def test_cloud_input_fast_path(D, oracle, tum_depth):
+    """process(pcd) / process_pcd_batch through the tuned organised-cloud kernel (P = 10, 4, 8), including the
+    reference's float64 Python-test cloud and a cloud that is NOT a back-projection (arbitrary xyz)."""
+    K = synth.read_K(synth.TUM_K)
+    intr = tuple(float(v) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2]))
+    full_compare(D, oracle, synth.tum_stream(3), intr, oracle.default_config(), xyz_api=True)
+    for patch in (4, 8, 10):
+        depth = synth.synth_batch(2, 240, 320, seed0=40 + patch)
+        full_compare(D, oracle, depth, synth.intrinsics_for(240, 320), oracle.default_config(patch_size=patch), xyz_api=True)
+    rng = np.random.default_rng(5)
+    h, w = 120, 160
+    base = oracle.backproject(synth.synth_depth(h, w, seed=3), *[np.float32(v) for v in synth.intrinsics_for(h, w)])
+    cloud = (base + rng.normal(scale=0.3, size=base.shape).astype(np.float32)).astype(np.float32)
+    cloud[rng.random(h * w) < 0.05] = 0
+    ex = D.PlaneExtractor(h, w)
+    got = ex.process(cloud)
+    oracle.set_math("devmath")
+    ol, oc, op, _, _ = oracle.process(oracle.default_config(), h, w, cloud, debug=True)
+    assert np.array_equal(got, ol)
+    assert_cells_equal(ex.cells(0), oc)
+    assert_planes_equal(ex.planes(0), op)
+
+
 def test_config_variants(D, oracle):
     depth = synth.synth_batch(2, 240, 320, seed0=5)
     intr = synth.intrinsics_for(240, 320)
