@@ -280,10 +280,17 @@ int run_pipeline3(dpx_handle h, const void* d_in, bool depth, int batch, float f
   // ---- stage 3: label expansion
   if (prof) DPX_HIP(hipEventRecord(ev[5], s_lab));
   {
-    const long long per_frame = static_cast<long long>(prm.H) * ((prm.W + 3) / 4);
-    const long long tot = per_frame * batch;
-    if (tot > 0)
-      hipLaunchKernelGGL(dpx::k_labels, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s_lab, prm, h->d_cell_labels, d_labels);
+    static const bool labels_v1 = std::getenv("DPX_LABELS_V1") != nullptr;
+    if ((prm.W & 3) == 0 && prm.nv + 1 <= 65535 && !labels_v1) {
+      const int extra = prm.H > prm.nv * prm.P ? 1 : 0;
+      if (prm.nv + extra > 0)
+        hipLaunchKernelGGL(dpx::k_labels_rows, dim3(batch, prm.nv + extra), dim3(256), 0, s_lab, prm, h->d_cell_labels, d_labels);
+    } else {
+      const long long per_frame = static_cast<long long>(prm.H) * ((prm.W + 3) / 4);
+      const long long tot = per_frame * batch;
+      if (tot > 0)
+        hipLaunchKernelGGL(dpx::k_labels, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s_lab, prm, h->d_cell_labels, d_labels);
+    }
   }
   if (prof) {
     DPX_HIP(hipEventRecord(ev[6], s_lab));

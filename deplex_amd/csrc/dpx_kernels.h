@@ -432,6 +432,56 @@ __global__ __launch_bounds__(256) void k_labels(Params prm, const int32_t* __res
   }
 }
 
+// K6, tuned form for W % 4 == 0: one 256-thread block per (frame, cell row).  The P image rows of a cell row carry the
+// same label pattern, so a thread builds its 4-pixel int4 once (labels of the cell row staged in LDS) and stores it to
+// all P rows: ~1 store per 16 output bytes and almost no arithmetic.  blockIdx.y == nv handles the image rows below
+// the last full cell row (H % P != 0), which are 0.
+__global__ __launch_bounds__(256) void k_labels_rows(Params prm, const int32_t* __restrict__ cell_labels, int32_t* __restrict__ labels) {
+  __shared__ int32_t cl[1024];
+  const int frame = blockIdx.x;
+  const int cr = blockIdx.y;
+  const int W4 = prm.W >> 2;
+  const bool tail = cr >= prm.nv;  // rows outside the cell grid
+  const int row_begin = tail ? prm.nv * prm.P : cr * prm.P;
+  const int row_end = tail ? prm.H : row_begin + prm.P;
+  const int32_t* src = cell_labels + static_cast<long long>(frame) * prm.C + static_cast<long long>(cr) * prm.nh;
+  int32_t* dst = labels + static_cast<long long>(frame) * prm.N;
+  for (int c0 = 0; c0 < prm.nh || c0 == 0; c0 += 1024) {  // cell rows wider than 1024 cells are processed in slabs
+    __syncthreads();
+    for (int c = threadIdx.x; c < 1024; c += 256) cl[c] = (!tail && c0 + c < prm.nh) ? src[c0 + c] : 0;
+    __syncthreads();
+    const int col_lo = c0 * prm.P, col_hi = (c0 + 1024) * prm.P;
+    for (int q = threadIdx.x; q < W4; q += 256) {
+      const int col = q << 2;
+      if (col + 3 < col_lo || col >= col_hi) continue;
+      if (col < col_lo || col + 3 >= col_hi) {  // chunk straddles a slab boundary (only for nh > 1024): scalar path
+        for (int i = 0; i < 4; ++i) {
+          const int cc = (col + i) / prm.P;
+          if (cc >= c0 && cc < c0 + 1024) {
+            const int32_t v = cl[cc - c0];
+            for (int r = row_begin; r < row_end; ++r) dst[static_cast<long long>(r) * prm.W + col + i] = v;
+          }
+        }
+        continue;
+      }
+      int cc = col / prm.P;
+      int rem = col - cc * prm.P;
+      int4 v;
+      int32_t* vp = reinterpret_cast<int32_t*>(&v);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        vp[i] = cl[cc - c0];
+        if (++rem == prm.P) {
+          rem = 0;
+          ++cc;
+        }
+      }
+      for (int r = row_begin; r < row_end; ++r) *reinterpret_cast<int4*>(dst + static_cast<long long>(r) * prm.W + col) = v;
+    }
+    if (prm.nh <= 1024) break;
+  }
+}
+
 // DepthImage::toPointCloud (utils/depth_image.cpp:55-78) as a stand-alone kernel for the utils API.
 __global__ __launch_bounds__(256) void k_backproject(const uint16_t* __restrict__ depth, int H, int W, float fx, float fy,
                                                      float cx, float cy, float* __restrict__ xyz) {
