@@ -16,6 +16,7 @@
 #include "dpx_planefit_fast.h"
 #include "dpx_regions.h"
 #include "dpx_regions2.h"
+#include "dpx_refine.h"
 
 namespace {
 
@@ -58,6 +59,8 @@ struct dpx_handle_s {
   uint2* d_pairs = nullptr;
   int32_t* d_merge = nullptr;
   dpx_frame_stats* d_stats = nullptr;
+  uint32_t* d_mt_init = nullptr;        // default-seeded mt19937 state for the RANSAC refinement
+  size_t refine_lds = 0;
   unsigned long long* d_dbg = nullptr;  // diagnostic phase stamps (dpx_debug_region_phases)
   float* d_mse_c = nullptr;
   uint32_t* d_cand_grow = nullptr;
@@ -108,6 +111,7 @@ void free_all(dpx_handle h) {
   hipFree(h->d_merge);
   hipFree(h->d_stats);
   hipFree(h->d_dbg);
+  hipFree(h->d_mt_init);
   hipFree(h->d_mse_c);
   hipFree(h->d_cand_grow);
   hipFree(h->d_gflags);
@@ -292,6 +296,21 @@ int run_pipeline3(dpx_handle h, const void* d_in, bool depth, int batch, float f
         hipLaunchKernelGGL(dpx::k_labels, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s_lab, prm, h->d_cell_labels, d_labels);
     }
   }
+  // ---- stage 4 (optional): RANSAC refinement of the label map (plane_extractor.cpp:265-279)
+  if (h->cfg.ransac_refinement && prm.C > 0) {
+    dpx::RefineArgs ra{};
+    ra.input = d_in;
+    ra.cell_labels = h->d_cell_labels;
+    ra.labels = d_labels;
+    ra.mt_init = h->d_mt_init;
+    ra.max_iter = h->cfg.ransac_max_iterations;
+    ra.thr = static_cast<double>(h->cfg.ransac_threshold);      // SetParamThreshold(double) <- float config value
+    ra.ratio = static_cast<double>(h->cfg.ransac_inliers_ratio);
+    if (depth)
+      hipLaunchKernelGGL(dpx::k_refine<true>, dim3(batch), dim3(dpx::kRefT), h->refine_lds, s_lab, prm, ra);
+    else
+      hipLaunchKernelGGL(dpx::k_refine<false>, dim3(batch), dim3(dpx::kRefT), h->refine_lds, s_lab, prm, ra);
+  }
   if (prof) {
     DPX_HIP(hipEventRecord(ev[6], s_lab));
     ++h->prof_calls;
@@ -456,8 +475,6 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
       image_width < 0)
     return fail(DPX_ERR_UNDEFINED,
                 "configuration undefined in the reference (negative patchSize, minPtsPerCell==0 or histogramBinsPerCoord<1)");
-  if (cfg->ransac_refinement)
-    return fail(DPX_ERR_UNDEFINED, "ransac_refinement is not implemented yet in this build");
   if (max_batch < 1) return fail(DPX_ERR_ARG, "max_batch must be >= 1");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -558,6 +575,20 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
                                : hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions<false>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds_bytes));
     if (e2 != hipSuccess) rc = fail(DPX_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e2));
+  }
+  if (rc == DPX_OK && cfg->ransac_refinement) {
+    uint32_t mt[624];
+    mt[0] = 5489u;  // std::mt19937 default seed
+    for (uint32_t i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + i;
+    A(dev_alloc(&h->d_mt_init, 624));
+    if (rc == DPX_OK && hipMemcpy(h->d_mt_init, mt, sizeof(mt), hipMemcpyHostToDevice) != hipSuccess) rc = fail(DPX_ERR_HIP, "hipMemcpy failed");
+    h->refine_lds = (624 + 32 + 16 + 2 * (static_cast<size_t>(nv) + 1) + C) * 4 + 64;
+    if (h->refine_lds > kLdsLimit) rc = fail(DPX_ERR_CAPACITY, "frame too large for the RANSAC refinement kernel's LDS cell list");
+    if (rc == DPX_OK && h->refine_lds > 48 * 1024) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_refine<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->refine_lds)) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_refine<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->refine_lds)) != hipSuccess)
+        rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
+    }
   }
   if (rc == DPX_OK && h->regions_tier > 0 && h->lds2_bytes > 48 * 1024) {
     hipError_t e3 = h->regions_tier == 2 ? hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<true, false>),
@@ -732,6 +763,7 @@ int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_
   }
   if (!enable && h->d_dbg) {
     hipFree(h->d_dbg);
+  hipFree(h->d_mt_init);
     h->d_dbg = nullptr;
   }
   return DPX_OK;

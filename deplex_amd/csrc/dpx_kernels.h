@@ -171,17 +171,38 @@ __device__ __forceinline__ void finish_cell(const Params& prm, int n, const floa
     const float nx = fit.normal[0], ny = fit.normal[1], nz = fit.normal[2];
     const bool is_zero = __builtin_fabsf(nx) <= 1e-5f && __builtin_fabsf(ny) <= 1e-5f && __builtin_fabsf(nz) <= 1e-5f;
     if (!is_zero) {
-      const double dnx = nx, dny = ny;
-      const double proj = dpxm::dsqrt(dnx * dnx + dny * dny);
-      const double polar = dpxm::dacos(static_cast<double>(-nz));
-      const double azim = dpxm::datan2(dnx / proj, dny / proj);
-      const double kPi = 3.14159265358979323846;
       const int B = prm.hist_B;
-      const int Xq = static_cast<int>((B - 1) * (polar - 0.0) / (kPi - 0.0));
-      int Yq = 0;
-      // azim is NaN only when nx == ny == 0; the reference then has Xq == 0 (normal (0,0,-1)) and never
-      // evaluates Yq, or reads out of bounds for a (0,0,+1) normal (undefined there; defined as 0 here).
-      if (Xq > 0 && azim == azim) Yq = static_cast<int>((B - 1) * (azim - (-kPi)) / (kPi - (-kPi)));
+      const double kPi = 3.14159265358979323846;
+      int Xq, Yq = 0;
+#if !defined(DPX_EXACT_BINS_ONLY)
+      // The bin indices are floors of (B-1)*angle/range.  A float32 estimate of the angles (acosf/atan2f, absolute
+      // error ~1e-6 rad, i.e. < 2e-5 after scaling for B <= 64) decides the floor whenever the scaled value is at
+      // least `margin` away from an integer — an order of magnitude more than the estimate's error plus the <1e-15
+      // error of the exact f64 evaluation — and
+      // only lanes closer than that to a bin edge (or with nx == ny == 0) take the exact f64 path below.  The result
+      // is therefore identical to evaluating the exact path for every cell; it just skips ~230 f64 instructions.
+      // (B <= 256 keeps the scaled estimate error below 2e-4.)
+      const float tX = static_cast<float>(B - 1) * acosf(-nz) * 0.318309886183790672f;
+      const float tY = static_cast<float>(B - 1) * (atan2f(nx, ny) + 3.14159265358979f) * 0.159154943091895336f;
+      const float fX = tX - __builtin_floorf(tX), fY = tY - __builtin_floorf(tY);
+      const float margin = B <= 64 ? 2e-4f : 1e-3f;  // >= 10x the estimate error in both regimes
+      const bool sureX = fX > margin && fX < 1.0f - margin;
+      const bool sureY = fY > margin && fY < 1.0f - margin && !(nx == 0.0f && ny == 0.0f);
+      if (sureX && sureY && B <= 256) {
+        Xq = static_cast<int>(tX);
+        if (Xq > 0) Yq = static_cast<int>(tY);
+      } else
+#endif
+      {
+        const double dnx = nx, dny = ny;
+        const double proj = dpxm::dsqrt(dnx * dnx + dny * dny);
+        const double polar = dpxm::dacos(static_cast<double>(-nz));
+        const double azim = dpxm::datan2(dnx / proj, dny / proj);
+        Xq = static_cast<int>((B - 1) * (polar - 0.0) / (kPi - 0.0));
+        // azim is NaN only when nx == ny == 0; the reference then has Xq == 0 (normal (0,0,-1)) and never
+        // evaluates Yq, or reads out of bounds for a (0,0,+1) normal (undefined there; defined as 0 here).
+        if (Xq > 0 && azim == azim) Yq = static_cast<int>((B - 1) * (azim - (-kPi)) / (kPi - (-kPi)));
+      }
       bin1 = static_cast<uint32_t>(Yq * B + Xq) + 1u;
     }
   }

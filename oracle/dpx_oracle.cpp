@@ -14,6 +14,8 @@
 #include <cstdio>
 #include <cstring>
 #include <queue>
+#include <random>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -409,6 +411,99 @@ struct Histogram {
   }
 };
 
+// ---- RANSAC refinement (plane_extractor.cpp:472-509, libs/rtl/include/rtl/{Plane,RANSAC}.hpp) ------------
+// The RNG (std::mt19937, default seed) and std::uniform_int_distribution<int> are the standard library's own,
+// exactly as the reference uses them: the draw sequence is that of the libstdc++ this file is compiled with
+// (GCC 11: Lemire's multiply-shift rejection for a 32-bit engine, bits/uniform_int_dist.h).
+struct PlaneModel {
+  float p[4];
+};
+
+// PlaneEstimator::ComputeModel (Plane.hpp:13-44): three points in ascending index order, all float32
+PlaneModel ransac_model(const float* P0, const float* P1, const float* P2) {
+  const float x0 = P0[0], x1 = P1[0], x2 = P2[0];
+  const float y0 = P0[1], y1 = P1[1], y2 = P2[1];
+  const float z0 = P0[2], z1 = P1[2], z2 = P2[2];
+  const float den = x0 * y1 - x1 * y0 - x0 * y2 + x2 * y0 + x1 * y2 - x2 * y1;
+  const float a = (z0 * (y1 - y2)) / den - (z1 * (y0 - y2)) / den + (z2 * (y0 - y1)) / den;
+  const float b = (z1 * (x0 - x2)) / den - (z0 * (x1 - x2)) / den - (z2 * (x0 - x1)) / den;
+  const float d = (z2 * (x0 * y1 - x1 * y0)) / den - (z1 * (x0 * y2 - x2 * y0)) / den + (z0 * (x1 * y2 - x2 * y1)) / den;
+  const float c = -1.0f;
+  const float l = static_cast<float>(std::sqrt(static_cast<double>(a * a + b * b + c * c)));
+  PlaneModel m;
+  m.p[0] = a / l;
+  m.p[1] = b / l;
+  m.p[2] = c / l;
+  m.p[3] = d / l;
+  return m;
+}
+
+// PlaneEstimator::ComputeError (Plane.hpp:46-49): float expression widened to double
+inline double ransac_error(const PlaneModel& m, const float* pt) {
+  return static_cast<double>(m.p[0] * pt[0] + m.p[1] * pt[1] + m.p[2] * pt[2] + m.p[3]);
+}
+
+struct RefineCounters {
+  int labels = 0;
+  long long iterations = 0;
+  long long zeroed = 0;
+};
+
+void refine_labels(const orc_config& cfg, const float* xyz, int64_t N, int32_t* labels, RefineCounters* rc) {
+  int32_t maxl = 0;
+  for (int64_t i = 0; i < N; ++i) maxl = std::max(maxl, labels[i]);  // labels->maxCoeff() (>= 0 here)
+  std::vector<std::vector<int32_t>> idx(static_cast<size_t>(maxl));
+  for (int64_t i = 0; i < N; ++i)
+    if (labels[i] != 0) idx[labels[i] - 1].push_back(static_cast<int32_t>(i));
+  std::mt19937 gen;  // one generator per process() call, default seed 5489 (RANSAC.hpp:111)
+  const int max_iter = cfg.ransac_max_iterations;
+  const double thr = cfg.ransac_threshold;
+  const double ratio = cfg.ransac_inliers_ratio;
+  for (int32_t l = 0; l < maxl; ++l) {
+    const int n = static_cast<int>(idx[l].size());
+    if (n == 0) continue;
+    if (rc) rc->labels++;
+    std::vector<float> pts(static_cast<size_t>(3) * n);
+    for (int r = 0; r < n; ++r) std::memcpy(&pts[3 * r], &xyz[3 * static_cast<int64_t>(idx[l][r])], 3 * sizeof(float));
+    // FindBest (RANSAC.hpp:25-51)
+    std::uniform_int_distribution<int> uni(0, n - 1);
+    PlaneModel best{{0.f, 0.f, 0.f, 0.f}};
+    double bestloss = HUGE_VAL;
+    int iteration = 0;
+    for (;;) {
+      // IsContinued(iteration, N - bestloss, N): the first call converts -inf to int (INT_MIN on x86-64)
+      const int inliers_count = std::isinf(bestloss) ? INT_MIN : static_cast<int>(n - bestloss);
+      if (!(iteration < max_iter && inliers_count < ratio * n)) break;
+      iteration++;
+      std::set<int> samples;
+      while (static_cast<int>(samples.size()) < 3) samples.insert(uni(gen));
+      auto it = samples.begin();
+      const int i0 = *it++, i1 = *it++, i2 = *it++;
+      const PlaneModel m = ransac_model(&pts[3 * i0], &pts[3 * i1], &pts[3 * i2]);
+      double loss = 0;
+      for (int r = 0; r < n; ++r) loss += (std::fabs(ransac_error(m, &pts[3 * r])) >= thr);
+      if (loss < bestloss) {
+        best = m;
+        bestloss = loss;
+      }
+    }
+    if (rc) rc->iterations += iteration;
+    // FindInliers (:53-62) + the relabel loop (plane_extractor.cpp:500-507): stops after the last inlier
+    std::vector<int> inliers;
+    for (int r = 0; r < n; ++r)
+      if (std::fabs(ransac_error(best, &pts[3 * r])) < thr) inliers.push_back(r);
+    size_t cur = 0;
+    for (int r = 0; r < n && cur < inliers.size(); ++r) {
+      if (inliers[cur] != r) {
+        labels[idx[l][r]] = 0;
+        if (rc) rc->zeroed++;
+      } else {
+        ++cur;
+      }
+    }
+  }
+}
+
 // ---- PlaneExtractor::Impl (plane_extractor.cpp) -------------------------------------------------
 struct Segment {
   Stat stat;
@@ -602,6 +697,8 @@ struct Extractor {
           labels[static_cast<int64_t>(row) * W + col] = lab;
         }
     }
+    // 7. refineLabels (:265-279), only when there are segments (the early return at :230-232 skips it)
+    if (cfg.ransac_refinement && !segs.empty()) refine_labels(cfg, xyz, N, labels, nullptr);
     // 8. cleanArtifacts (:281)
     std::fill(labels_map.begin(), labels_map.end(), 0);
 

@@ -370,3 +370,41 @@ def test_multistream_pipeline(D, oracle):
         assert ms["planefit"] > 0 and ms["regions"] > 0 and ms["labels"] > 0
         assert pipe.slot((steps - 1) % 3).frame_stats(0)["segments"] >= 0
         del pipe
+
+
+def test_ransac_refinement_parity(D, oracle, tum_depth, icl_depth):
+    """refineLabels (plane_extractor.cpp:472-509) on the device: same label maps as the oracle (which uses
+    std::mt19937 / std::uniform_int_distribution directly), through the depth and the cloud entry points, plus the
+    reference's own invariant (cpp/tests/test_refinement.cpp:43-75)."""
+    oracle.set_math("devmath")
+    cases = [(tum_depth, synth.TUM_K, synth.TUM_INI), (icl_depth, synth.ICL_K, synth.ICL_INI)]
+    for depth, kpath, ini in cases:
+        K = synth.read_K(kpath)
+        intr = tuple(float(v) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2]))
+        pts = oracle.backproject(depth, K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+        ocfg = oracle.config_from_ini(ini)
+        coarse = oracle.process(ocfg, 480, 640, pts)
+        ocfg.ransac_refinement = 1
+        ref = oracle.process(ocfg, 480, 640, pts)
+        cfg = D.Config(str(ini))
+        cfg.ransac_refinement = True
+        ex = D.PlaneExtractor(480, 640, cfg)
+        got_depth = ex.process_depth_batch(depth[None], *intr)[0]
+        got_cloud = ex.process(pts)
+        assert np.array_equal(got_depth, ref) and np.array_equal(got_cloud, ref)
+
+        def mse(lab):
+            p = np.ascontiguousarray(pts[lab == 1])
+            return float(oracle.lib().orc_points_mse(p.ctypes.data, p.shape[0]))
+        assert mse(got_cloud) <= mse(coarse)
+    # batches of synthetic frames, few iterations and a loose threshold so that several labels run the full loop
+    depth = synth.synth_batch(3, 240, 320, seed0=60)
+    intr = synth.intrinsics_for(240, 320)
+    for ov in ({"ransac_max_iterations": 50, "ransac_threshold": 4.0, "ransac_inliers_ratio": 0.9},
+               {"ransac_max_iterations": 7, "ransac_threshold": 0.5, "ransac_inliers_ratio": 1.5}):
+        ocfg = oracle.default_config(ransac_refinement=1, **ov)
+        ex = D.PlaneExtractor(240, 320, to_cfg(D, ocfg), max_batch=3)
+        got = ex.process_depth_batch(depth, *intr)
+        for k in range(3):
+            ref = oracle.process(ocfg, 240, 320, oracle.backproject(depth[k], *[np.float32(v) for v in intr]))
+            assert np.array_equal(got[k], ref), (ov, k)

@@ -207,3 +207,23 @@ def test_frame_parallel_batch_matches_single(oracle):
     assert np.array_equal(a, b)
     single = oracle.process(oracle.default_config(), 240, 320, oracle.backproject(d[2], fx, fy, cx, cy))
     assert np.array_equal(a[2], single)
+
+
+@pytest.mark.parametrize("which", ["tum", "icl"])
+def test_refinement_reduces_plane_mse(oracle, tum_depth, icl_depth, which):
+    """cpp/tests/test_refinement.cpp:43-75 — with RANSAC refinement on, the MSE of the points labelled 1 does not
+    increase (TUM and ICL with their .ini files)."""
+    depth, kpath, ini = (tum_depth, synth.TUM_K, synth.TUM_INI) if which == "tum" else (icl_depth, synth.ICL_K, synth.ICL_INI)
+    K = synth.read_K(kpath)
+    pts = oracle.backproject(depth, K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+    cfg = oracle.config_from_ini(ini)
+    coarse = oracle.process(cfg, 480, 640, pts)
+    cfg.ransac_refinement = 1
+    refined = oracle.process(cfg, 480, 640, pts)
+
+    def mse(lab):
+        p = np.ascontiguousarray(pts[lab == 1])
+        return float(oracle.lib().orc_points_mse(p.ctypes.data, p.shape[0]))
+    assert mse(refined) <= mse(coarse)
+    assert set(np.unique(refined)) <= set(np.unique(coarse))  # refinement only removes pixels from planes
+    assert np.all((refined == coarse) | (refined == 0))
