@@ -1,0 +1,48 @@
+// deplex/utils/depth_image.h — C++ mirror of deplex::utils::DepthImage (cpp/deplex/include/deplex/utils/depth_image.h:24-56).
+// The back-projection arithmetic (utils/depth_image.cpp:55-78) runs in the HIP kernel behind dpx_backproject.
+// PNG decoding is file IO and outside the accelerated path (the reference vendors stb_image for it): this mirror is
+// constructed from a decoded 16-bit buffer; readIntrinsics mirrors utils/eigen_io.cpp:41-55.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <fstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../../../include/deplex_amd.h"
+
+namespace deplex {
+namespace utils {
+/** 3x3 intrinsics, row-major (K(i,j) = k[3*i+j]). */
+using Intrinsics = std::array<float, 9>;
+
+inline Intrinsics readIntrinsics(std::string const& intrinsics_path) {
+  std::ifstream in(intrinsics_path);
+  if (!in.is_open()) throw std::runtime_error("Error: Couldn't open intrinsics file " + intrinsics_path);
+  Intrinsics K{};
+  for (int i = 0; i < 9; ++i) in >> K[i];
+  return K;
+}
+
+class DepthImage {
+ public:
+  DepthImage() : width_(0), height_(0) {}
+  DepthImage(uint16_t const* data, int32_t height, int32_t width) : image_(data, data + static_cast<size_t>(height) * width), width_(width), height_(height) {}
+  int32_t getWidth() const { return width_; }
+  int32_t getHeight() const { return height_; }
+  uint16_t const* data() const { return image_.data(); }
+  /** N x 3 row-major float cloud; z in raw depth units (no scaling), like the reference. */
+  std::vector<float> toPointCloud(Intrinsics const& K, int32_t device = 0) const {
+    std::vector<float> xyz(static_cast<size_t>(3) * width_ * height_);
+    if (dpx_backproject(image_.data(), height_, width_, K[0], K[4], K[2], K[5], xyz.data(), device) != DPX_OK)
+      throw std::runtime_error(dpx_last_error());
+    return xyz;
+  }
+
+ private:
+  std::vector<uint16_t> image_;
+  int32_t width_, height_;
+};
+}  // namespace utils
+}  // namespace deplex

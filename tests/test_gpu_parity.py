@@ -408,3 +408,22 @@ def test_ransac_refinement_parity(D, oracle, tum_depth, icl_depth):
         for k in range(3):
             ref = oracle.process(ocfg, 240, 320, oracle.backproject(depth[k], *[np.float32(v) for v in intr]))
             assert np.array_equal(got[k], ref), (ov, k)
+
+
+def test_cpp_mirror_known_answer(tmp_path, tum_depth):
+    """The C++ mirror API end to end on the GPU: TUM frame -> 34 planes (cpp/tests/test_plane_extractor.cpp:27-33) and
+    the reference's two std::runtime_error cases (:47-53, :83-88)."""
+    import subprocess
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from test_host_api import build_cpp_example
+    exe = build_cpp_example(tmp_path)
+    raw = tmp_path / "tum.u16"
+    tum_depth.astype("<u2").tofile(raw)
+    r = subprocess.run([str(exe), str(raw), "480", "640", str(synth.TUM_K)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "planes 34 labels 307200" in r.stdout
+    assert "throws: Error! Invalid config parameter: patchSize(0). patchSize has to be positive." in r.stdout
+    assert "throws: Error! Number of points doesn't match image shape: 307200 != 240 x 320" in r.stdout
+    r = subprocess.run([str(exe), str(raw), "480", "640", str(synth.TUM_K), "/nonexistent.ini"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "Couldn't open ini file: /nonexistent.ini" in r.stderr
