@@ -106,10 +106,17 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False and there is no CPU path")
+    # DPX_BENCH_SINGLE_DEVICE=1 + DPX_BENCH_BACKEND=gloo rehearse the N>1 code path on a one-GPU box (tests only)
+    if os.environ.get("DPX_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("DPX_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     import deplex_amd as D
 
     depth, intr, wl_desc = make_workload(args.workload, args.batch, rank)
@@ -151,7 +158,7 @@ def main():
         return
     elapsed = timed_region(step, sync, barrier, args.steps, args.warmup)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -427,3 +427,23 @@ def test_cpp_mirror_known_answer(tmp_path, tum_depth):
     assert "throws: Error! Number of points doesn't match image shape: 307200 != 240 x 320" in r.stdout
     r = subprocess.run([str(exe), str(raw), "480", "640", str(synth.TUM_K), "/nonexistent.ini"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 1 and "Couldn't open ini file: /nonexistent.ini" in r.stderr
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """Rehearsal of `bench.py --gpus 2` (the driver launches it through torch.distributed.run): two ranks, both on
+    GPU 0, gloo for the barrier / MAX reduction.  Checks the JSON contract of the N>1 line."""
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, DPX_BENCH_SINGLE_DEVICE="1", DPX_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", str(root / "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--streams", "4",
+           "--no-cloud-roofline", "--roofline-iters", "5"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["scaling"] == "weak" and d["unit"] == "frames/s"
+    assert d["value"] > 0 and abs(d["value"] - 2 * 64 * 8 / (d["ms_per_step"] * 8e-3)) / d["value"] < 0.02
+    assert "cpu_baseline" not in d and d["roofline"]["frac"] > 0 and d["parity"].startswith("bit-exact")
