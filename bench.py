@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DPX_BENCH_STREAMS", 16)))
-    ap.add_argument("--region-streams", type=int, default=0, help="0: one stream per batch in flight (default); >0: staged mode")
+    ap.add_argument("--group", type=int, default=int(os.environ.get("DPX_BENCH_GROUP", 4)), help="submissions per region-growing launch")
     ap.add_argument("--prof-every", type=int, default=8, help="record per-kernel HIP events on every n-th slot")
     ap.add_argument("--roofline-iters", type=int, default=50)
     ap.add_argument("--no-cloud-roofline", action="store_true")
@@ -125,8 +125,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
     S = max(1, args.streams)  # batches in flight (pipeline slots), one stream each
-    d_labels = torch.empty((S, B, N), dtype=torch.int32, device=dev)
-    pipe = D.Pipeline(H, W, D.Config(), batch=B, slots=S, region_streams=args.region_streams, device=local_rank)
+    G = max(1, min(8, args.group))
+    d_labels = torch.empty((S * G, B, N), dtype=torch.int32, device=dev)
+    pipe = D.Pipeline(H, W, D.Config(), batch=B, slots=S, group=args.group, device=local_rank)
     exs = [pipe.slot(k) for k in range(S)]
     for ex in exs:
         ex.prepare_intrinsics(*intr)  # one-time exact-division check, outside the timed region
@@ -137,7 +138,7 @@ def main():
         exs[k].set_profiling(True)
 
     def step(i):
-        pipe.submit_depth(d_depth.data_ptr(), B, *intr, d_labels[i % S].data_ptr())
+        pipe.submit_depth(d_depth.data_ptr(), B, *intr, d_labels[i % (S * G)].data_ptr())
 
     def sync():
         pipe.sync()
@@ -191,7 +192,7 @@ def main():
         from oracle import oracle as O
         O.set_math("devmath")
         nchk = min(args.parity_frames, B)
-        got = d_labels[(args.steps - 1) % S, :nchk].cpu().numpy()
+        got = d_labels[(args.steps - 1) % (S * G), :nchk].cpu().numpy()
         ref = O.process_depth_batch(O.default_config(), depth[:nchk], *intr, threads=min(nchk, os.cpu_count() or 1))
         if not np.array_equal(got, ref):
             raise SystemExit("bench: HIP label maps differ from the oracle — refusing to report a number")
@@ -218,7 +219,7 @@ def main():
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl_desc, "patch_size": 10, "batch_per_gpu": B, "batches_in_flight": S,
+            "config": {"workload": wl_desc, "patch_size": 10, "batch_per_gpu": B, "groups_in_flight": S, "batches_per_region_launch": G,
                        "streams": f"{S} (one per batch in flight), GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}",
                        "arithmetic": "f32 moments (reference order), f64 3x3 eigen, int32 labels",
                        "parallelism": f"frame-shard x{world}, no collectives"},

@@ -62,6 +62,8 @@ struct dpx_handle_s {
   uint32_t* d_mt_init = nullptr;        // default-seeded mt19937 state for the RANSAC refinement
   size_t refine_lds = 0;
   unsigned long long* d_dbg = nullptr;  // diagnostic phase stamps (dpx_debug_region_phases)
+  float4* d_lds_img = nullptr;          // split region kernel: LDS image per frame
+  bool regions_split = false;
   float* d_mse_c = nullptr;
   uint32_t* d_cand_grow = nullptr;
   int regions_tier = 0;  // 2 = k_regions2<FULL>, 1 = k_regions2<LEAN>, 0 = k_regions (v1)
@@ -82,8 +84,7 @@ struct dpx_handle_s {
   bool profiling = false;
   static constexpr int kProfSlots = 128;
   hipEvent_t ev[kProfSlots][7] = {};  // fit start/end, graph start, graph end = regions start, regions end, labels start/end
-  hipEvent_t ev_sync[3] = {};          // stage hand-off events for multi-stream pipelines
-  bool sync_recorded = false;
+  float last_intr[4] = {1.f, 1.f, 0.f, 0.f};  // intrinsics of the last plane fit (the refinement re-projects with them)
   bool ev_created = false;
   long long prof_calls = 0;
   int last_batch = 0;
@@ -112,6 +113,7 @@ void free_all(dpx_handle h) {
   hipFree(h->d_stats);
   hipFree(h->d_dbg);
   hipFree(h->d_mt_init);
+  hipFree(h->d_lds_img);
   hipFree(h->d_mse_c);
   hipFree(h->d_cand_grow);
   hipFree(h->d_gflags);
@@ -123,8 +125,6 @@ void free_all(dpx_handle h) {
   for (auto& slot : h->ev)
     for (auto& e : slot)
       if (e) hipEventDestroy(e);
-  for (auto& e : h->ev_sync)
-    if (e) hipEventDestroy(e);
   if (h->stream) hipStreamDestroy(h->stream);
 }
 
@@ -171,7 +171,7 @@ void launch_planefit_fast(const dpx::Params& prm, const void* d_in, dpx_cell* d_
     hipLaunchKernelGGL((dpx::k_planefit_depth<P, false>), dim3(blocks), dim3(256), 0, s, prm, static_cast<const uint16_t*>(d_in), d_cells, rx, ry);
 }
 
-void launch_planefit_depth(dpx_handle h, const dpx::Params& prm, const void* d_in, hipStream_t s);
+void launch_planefit_depth(dpx_handle h, const dpx::Params& prm, const void* d_in, dpx_cell* d_cells, hipStream_t s);
 
 template <bool DEPTH>
 void launch_planefit(const dpx::Params& prm, const void* d_in, dpx_cell* d_cells, hipStream_t s) {
@@ -187,137 +187,168 @@ void launch_planefit(const dpx::Params& prm, const void* d_in, dpx_cell* d_cells
   }
 }
 
-void launch_planefit_cloud(dpx_handle h, const dpx::Params& prm, const void* d_in, hipStream_t s) {
+void launch_planefit_cloud(dpx_handle h, const dpx::Params& prm, const void* d_in, dpx_cell* d_cells, hipStream_t s) {
   const char* v1 = std::getenv("DPX_PLANEFIT_V1");
   if (fast_shape(prm) && !(v1 && v1[0] == '1')) {
     const long long waves = static_cast<long long>(prm.batch) * prm.nv * ((prm.nh + 63) / 64);
     const unsigned blocks = static_cast<unsigned>((waves + 3) / 4);
     const float* xyz = static_cast<const float*>(d_in);
     switch (prm.P) {
-      case 4: hipLaunchKernelGGL((dpx::k_planefit_cloud<4>), dim3(blocks), dim3(256), 0, s, prm, xyz, h->d_cells); return;
-      case 8: hipLaunchKernelGGL((dpx::k_planefit_cloud<8>), dim3(blocks), dim3(256), 0, s, prm, xyz, h->d_cells); return;
-      case 10: hipLaunchKernelGGL((dpx::k_planefit_cloud<10>), dim3(blocks), dim3(256), 0, s, prm, xyz, h->d_cells); return;
+      case 4: hipLaunchKernelGGL((dpx::k_planefit_cloud<4>), dim3(blocks), dim3(256), 0, s, prm, xyz, d_cells); return;
+      case 8: hipLaunchKernelGGL((dpx::k_planefit_cloud<8>), dim3(blocks), dim3(256), 0, s, prm, xyz, d_cells); return;
+      case 10: hipLaunchKernelGGL((dpx::k_planefit_cloud<10>), dim3(blocks), dim3(256), 0, s, prm, xyz, d_cells); return;
       default: break;
     }
   }
-  launch_planefit<false>(prm, d_in, h->d_cells, s);
+  launch_planefit<false>(prm, d_in, d_cells, s);
 }
 
-void launch_planefit_depth(dpx_handle h, const dpx::Params& prm, const void* d_in, hipStream_t s) {
+void launch_planefit_depth(dpx_handle h, const dpx::Params& prm, const void* d_in, dpx_cell* d_cells, hipStream_t s) {
   const char* v1 = std::getenv("DPX_PLANEFIT_V1");
   if (fast_shape(prm) && !(v1 && v1[0] == '1')) {
     switch (prm.P) {
-      case 4: launch_planefit_fast<4>(prm, d_in, h->d_cells, s, h->fd_ok, h->fd_rx, h->fd_ry); return;
-      case 8: launch_planefit_fast<8>(prm, d_in, h->d_cells, s, h->fd_ok, h->fd_rx, h->fd_ry); return;
-      case 10: launch_planefit_fast<10>(prm, d_in, h->d_cells, s, h->fd_ok, h->fd_rx, h->fd_ry); return;
+      case 4: launch_planefit_fast<4>(prm, d_in, d_cells, s, h->fd_ok, h->fd_rx, h->fd_ry); return;
+      case 8: launch_planefit_fast<8>(prm, d_in, d_cells, s, h->fd_ok, h->fd_rx, h->fd_ry); return;
+      case 10: launch_planefit_fast<10>(prm, d_in, d_cells, s, h->fd_ok, h->fd_rx, h->fd_ry); return;
       default: break;
     }
   }
-  launch_planefit<true>(prm, d_in, h->d_cells, s);
+  launch_planefit<true>(prm, d_in, d_cells, s);
 }
 
-// One batch through the three stages.  With a single stream the stages are ordered by the stream; with distinct
-// streams (dpx_pipeline) the handle's events order them: plane fit on s_fit, region growing on s_reg, label expansion
-// on s_lab, and the next use of this handle's scratch waits for the previous label expansion.
-int run_pipeline3(dpx_handle h, const void* d_in, bool depth, int batch, float fx, float fy, float cx, float cy,
-                  int32_t* d_labels, hipStream_t s_fit, hipStream_t s_reg, hipStream_t s_lab) {
-  if (batch < 0 || batch > h->max_batch)
-    return fail(DPX_ERR_ARG, "batch " + std::to_string(batch) + " exceeds max_batch " + std::to_string(h->max_batch));
+// A batch goes through two host-side stages on one stream:
+//   stage_fit  : plane fit of `batch` frames into the handle's cell records at frame offset `frame_off`
+//   stage_rest : region growing (+ cell graph for the fallback tiers), label expansion (fused into the region kernel's
+//                tail when possible) and the optional refinement for `nsub` sub-batches of `per_sub` frames that were
+//                fitted before — one launch for all of them (dpx_pipeline groups several submissions this way: the GPU
+//                runs only ~6-7 kernels concurrently, so a latency-bound region launch per 64 frames wastes kernel slots).
+struct SubBatch {
+  const void* d_in;
+  int32_t* d_labels;
+};
+
+int stage_fit(dpx_handle h, const void* d_in, bool depth, int batch, float fx, float fy, float cx, float cy, int frame_off,
+              hipStream_t s) {
+  if (batch < 0 || frame_off < 0 || frame_off + batch > h->max_batch)
+    return fail(DPX_ERR_ARG, "batch " + std::to_string(frame_off + batch) + " exceeds max_batch " + std::to_string(h->max_batch));
   DPX_HIP(hipSetDevice(h->device));
-  h->last_stream = s_lab;
-  h->last_batch = batch;
   if (batch == 0) return DPX_OK;
   if (depth) {
     const int rcp = prepare_intrinsics(h, fx, fy, cx, cy);
     if (rcp) return rcp;
   }
-  const bool multi = (s_fit != s_reg) || (s_reg != s_lab);
-  if (multi && !h->ev_sync[0]) {
-    for (auto& e : h->ev_sync) DPX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  }
   dpx::Params prm = h->prm;
   prm.batch = batch;
   prm.fx = fx; prm.fy = fy; prm.cx = cx; prm.cy = cy;
+  h->last_intr[0] = fx; h->last_intr[1] = fy; h->last_intr[2] = cx; h->last_intr[3] = cy;
   const bool prof = h->profiling;
   hipEvent_t* ev = h->ev[h->prof_calls % dpx_handle_s::kProfSlots];
-  if (multi && h->sync_recorded) DPX_HIP(hipStreamWaitEvent(s_fit, h->ev_sync[2], 0));
-  // ---- stage 1: plane fit
-  if (prof) DPX_HIP(hipEventRecord(ev[0], s_fit));
-  if (prm.C > 0) {
+  // DPX_SKIP=<letters f r l>: timing-only diagnostics that leave out a stage (results are garbage); tools/stage_cost.sh
+  static const char* skip = std::getenv("DPX_SKIP");
+  const bool skip_f = skip && std::strchr(skip, 'f');
+  if (prof) DPX_HIP(hipEventRecord(ev[0], s));
+  if (prm.C > 0 && !skip_f) {
+    dpx_cell* out = h->d_cells + static_cast<size_t>(frame_off) * prm.C;
     if (depth)
-      launch_planefit_depth(h, prm, d_in, s_fit);
+      launch_planefit_depth(h, prm, d_in, out, s);
     else
-      launch_planefit_cloud(h, prm, d_in, s_fit);
+      launch_planefit_cloud(h, prm, d_in, out, s);
   }
-  if (prof) DPX_HIP(hipEventRecord(ev[1], s_fit));
-  if (multi) {
-    DPX_HIP(hipEventRecord(h->ev_sync[0], s_fit));
-    DPX_HIP(hipStreamWaitEvent(s_reg, h->ev_sync[0], 0));
-  }
-  // ---- stage 2: cell graph (only when the region kernel does not compute it itself) + region growing
-  if (prof) DPX_HIP(hipEventRecord(ev[2], s_reg));
+  if (prof) DPX_HIP(hipEventRecord(ev[1], s));
+  return DPX_OK;
+}
+
+int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool depth, hipStream_t s) {
+  const int batch = nsub * per_sub;
+  if (nsub < 1 || nsub > 8 || batch > h->max_batch) return fail(DPX_ERR_ARG, "bad sub-batch grouping");
+  DPX_HIP(hipSetDevice(h->device));
+  h->last_stream = s;
+  h->last_batch = batch;
+  if (batch == 0) return DPX_OK;
+  dpx::Params prm = h->prm;
+  prm.batch = batch;
+  prm.fx = h->last_intr[0]; prm.fy = h->last_intr[1]; prm.cx = h->last_intr[2]; prm.cy = h->last_intr[3];
+  const bool prof = h->profiling;
+  hipEvent_t* ev = h->ev[h->prof_calls % dpx_handle_s::kProfSlots];
+  static const char* skip = std::getenv("DPX_SKIP");
+  const bool skip_r = skip && std::strchr(skip, 'r'), skip_l = skip && std::strchr(skip, 'l');
+  // ---- cell graph (only when the region kernel does not compute it itself) + region growing
+  if (prof) DPX_HIP(hipEventRecord(ev[2], s));
   const long long total = static_cast<long long>(batch) * prm.C;
   if (total > 0 && h->regions_tier != 2)
-    hipLaunchKernelGGL(dpx::k_cellgraph, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s_reg, prm, h->d_cells, h->d_meta, h->d_mse_c);
-  if (prof) DPX_HIP(hipEventRecord(ev[3], s_reg));
+    hipLaunchKernelGGL(dpx::k_cellgraph, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, prm, h->d_cells, h->d_meta, h->d_mse_c);
+  if (prof) DPX_HIP(hipEventRecord(ev[3], s));
   dpx::RegionBufs rb{};
   rb.cells = h->d_cells; rb.meta = h->d_meta; rb.order = h->d_order; rb.grow_start = h->d_grow_start;
   rb.cand = h->d_cand; rb.planes = h->d_planes; rb.cell_labels = h->d_cell_labels; rb.pairs = h->d_pairs;
   rb.merge = h->d_merge; rb.stats = h->d_stats; rb.g_flags = h->d_gflags; rb.g_owner = h->d_gowner;
   rb.g_queue = h->d_gqueue; rb.pcap = h->pcap;
-  dpx::Regions2Extra rx{h->d_mse_c, h->d_cand_grow, h->d_dbg};
-  if (h->regions_tier == 2 && h->d_dbg)
-    hipLaunchKernelGGL((dpx::k_regions2<true, true>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s_reg, prm, rb, rx);
-  else if (h->regions_tier == 2)
-    hipLaunchKernelGGL((dpx::k_regions2<true, false>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s_reg, prm, rb, rx);
+  // the region kernel's tail can write the pixel label map itself (no separate label-expansion launch)
+  static const bool nofuse = std::getenv("DPX_NO_FUSED_LABELS") != nullptr;
+  const bool fuse_labels = h->regions_tier == 2 && (prm.W & 3) == 0 && !nofuse && !skip_l && !skip_r;
+  dpx::Regions2Extra rx{};
+  rx.mse_c = h->d_mse_c; rx.cand_grow = h->d_cand_grow; rx.dbg = h->d_dbg; rx.lds_img = h->d_lds_img;
+  rx.img_bytes = static_cast<int>((h->lds2_bytes + 15) & ~size_t(15));
+  rx.frames_per_out = per_sub;
+  for (int j = 0; j < 8; ++j) rx.labels_out[j] = (fuse_labels && j < nsub) ? subs[j].d_labels : nullptr;
+  if (skip_r) {
+  } else if (h->regions_tier == 2 && h->d_dbg)
+    hipLaunchKernelGGL((dpx::k_regions2<true, true, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
+  else if (h->regions_tier == 2 && h->regions_split) {
+    hipLaunchKernelGGL((dpx::k_regions2<true, false, 1>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<true, false, 2>), dim3(batch), dim3(64), h->lds2_bytes, s, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<true, false, 3>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
+  } else if (h->regions_tier == 2)
+    hipLaunchKernelGGL((dpx::k_regions2<true, false, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
   else if (h->regions_tier == 1)
-    hipLaunchKernelGGL((dpx::k_regions2<false, false>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s_reg, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<false, false, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
   else if (h->use_lds)
-    hipLaunchKernelGGL(dpx::k_regions<true>, dim3(batch), dim3(64), h->lds_bytes, s_reg, prm, rb);
+    hipLaunchKernelGGL(dpx::k_regions<true>, dim3(batch), dim3(64), h->lds_bytes, s, prm, rb);
   else
-    hipLaunchKernelGGL(dpx::k_regions<false>, dim3(batch), dim3(64), h->lds_bytes, s_reg, prm, rb);
-  if (prof) DPX_HIP(hipEventRecord(ev[4], s_reg));
-  if (multi) {
-    DPX_HIP(hipEventRecord(h->ev_sync[1], s_reg));
-    DPX_HIP(hipStreamWaitEvent(s_lab, h->ev_sync[1], 0));
-  }
-  // ---- stage 3: label expansion
-  if (prof) DPX_HIP(hipEventRecord(ev[5], s_lab));
-  {
+    hipLaunchKernelGGL(dpx::k_regions<false>, dim3(batch), dim3(64), h->lds_bytes, s, prm, rb);
+  if (prof) DPX_HIP(hipEventRecord(ev[4], s));
+  // ---- label expansion (per sub-batch: each has its own output buffer)
+  if (prof) DPX_HIP(hipEventRecord(ev[5], s));
+  if (!skip_l && !fuse_labels) {
     static const bool labels_v1 = std::getenv("DPX_LABELS_V1") != nullptr;
-    if ((prm.W & 3) == 0 && prm.nv + 1 <= 65535 && !labels_v1) {
-      const int extra = prm.H > prm.nv * prm.P ? 1 : 0;
-      if (prm.nv + extra > 0)
-        hipLaunchKernelGGL(dpx::k_labels_rows, dim3(batch, prm.nv + extra), dim3(256), 0, s_lab, prm, h->d_cell_labels, d_labels);
-    } else {
-      const long long per_frame = static_cast<long long>(prm.H) * ((prm.W + 3) / 4);
-      const long long tot = per_frame * batch;
-      if (tot > 0)
-        hipLaunchKernelGGL(dpx::k_labels, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s_lab, prm, h->d_cell_labels, d_labels);
+    dpx::Params ps = prm;
+    ps.batch = per_sub;
+    for (int j = 0; j < nsub; ++j) {
+      const int32_t* cl = h->d_cell_labels + static_cast<size_t>(j) * per_sub * prm.C;
+      if ((prm.W & 3) == 0 && prm.nv + 1 <= 65535 && !labels_v1) {
+        const int extra = prm.H > prm.nv * prm.P ? 1 : 0;
+        if (prm.nv + extra > 0)
+          hipLaunchKernelGGL(dpx::k_labels_rows, dim3(per_sub, prm.nv + extra), dim3(256), 0, s, ps, cl, subs[j].d_labels);
+      } else {
+        const long long per_frame = static_cast<long long>(prm.H) * ((prm.W + 3) / 4);
+        const long long tot = per_frame * per_sub;
+        if (tot > 0)
+          hipLaunchKernelGGL(dpx::k_labels, dim3(static_cast<unsigned>((tot + 255) / 256)), dim3(256), 0, s, ps, cl, subs[j].d_labels);
+      }
     }
   }
-  // ---- stage 4 (optional): RANSAC refinement of the label map (plane_extractor.cpp:265-279)
+  // ---- optional: RANSAC refinement of the label map (plane_extractor.cpp:265-279)
   if (h->cfg.ransac_refinement && prm.C > 0) {
-    dpx::RefineArgs ra{};
-    ra.input = d_in;
-    ra.cell_labels = h->d_cell_labels;
-    ra.labels = d_labels;
-    ra.mt_init = h->d_mt_init;
-    ra.max_iter = h->cfg.ransac_max_iterations;
-    ra.thr = static_cast<double>(h->cfg.ransac_threshold);      // SetParamThreshold(double) <- float config value
-    ra.ratio = static_cast<double>(h->cfg.ransac_inliers_ratio);
-    if (depth)
-      hipLaunchKernelGGL(dpx::k_refine<true>, dim3(batch), dim3(dpx::kRefT), h->refine_lds, s_lab, prm, ra);
-    else
-      hipLaunchKernelGGL(dpx::k_refine<false>, dim3(batch), dim3(dpx::kRefT), h->refine_lds, s_lab, prm, ra);
+    dpx::Params ps = prm;
+    ps.batch = per_sub;
+    for (int j = 0; j < nsub; ++j) {
+      dpx::RefineArgs ra{};
+      ra.input = subs[j].d_in;
+      ra.cell_labels = h->d_cell_labels + static_cast<size_t>(j) * per_sub * prm.C;
+      ra.labels = subs[j].d_labels;
+      ra.mt_init = h->d_mt_init;
+      ra.max_iter = h->cfg.ransac_max_iterations;
+      ra.thr = static_cast<double>(h->cfg.ransac_threshold);      // SetParamThreshold(double) <- float config value
+      ra.ratio = static_cast<double>(h->cfg.ransac_inliers_ratio);
+      if (depth)
+        hipLaunchKernelGGL(dpx::k_refine<true>, dim3(per_sub), dim3(dpx::kRefT), h->refine_lds, s, ps, ra);
+      else
+        hipLaunchKernelGGL(dpx::k_refine<false>, dim3(per_sub), dim3(dpx::kRefT), h->refine_lds, s, ps, ra);
+    }
   }
   if (prof) {
-    DPX_HIP(hipEventRecord(ev[6], s_lab));
+    DPX_HIP(hipEventRecord(ev[6], s));
     ++h->prof_calls;
-  }
-  if (multi) {
-    DPX_HIP(hipEventRecord(h->ev_sync[2], s_lab));
-    h->sync_recorded = true;
   }
   DPX_HIP(hipGetLastError());
   return DPX_OK;
@@ -325,7 +356,15 @@ int run_pipeline3(dpx_handle h, const void* d_in, bool depth, int batch, float f
 
 int run_pipeline(dpx_handle h, const void* d_in, bool depth, int batch, float fx, float fy, float cx, float cy,
                  int32_t* d_labels, hipStream_t s) {
-  return run_pipeline3(h, d_in, depth, batch, fx, fy, cx, cy, d_labels, s, s, s);
+  if (batch < 0 || batch > h->max_batch)
+    return fail(DPX_ERR_ARG, "batch " + std::to_string(batch) + " exceeds max_batch " + std::to_string(h->max_batch));
+  h->last_stream = s;
+  h->last_batch = batch;
+  if (batch == 0) return DPX_OK;
+  int rc = stage_fit(h, d_in, depth, batch, fx, fy, cx, cy, 0, s);
+  if (rc) return rc;
+  const SubBatch sb{d_in, d_labels};
+  return stage_rest(h, &sb, 1, batch, depth, s);
 }
 
 int ensure_staging(dpx_handle h, size_t in_bytes, size_t label_bytes) {
@@ -533,7 +572,7 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
                                                       : static_cast<long long>(C) / cfg->min_region_growing_cells_activated));
   {
     // region-growing kernel tier: everything in LDS (13 B/cell), lean (7 B/cell), or the v1 kernel
-    const size_t fixed = 192 + hist_bytes + static_cast<size_t>(dpx::kRW) * 64 * 9 * 4 + 64;
+    const size_t fixed = 192 + static_cast<size_t>(2 * nb) * 4 + static_cast<size_t>(nb + 2) * 2 + static_cast<size_t>(dpx::kStageFloats) * 4 + 16;
     const char* v1 = std::getenv("DPX_REGIONS_V1");
     const char* lean = std::getenv("DPX_REGIONS_LEAN");
     h->regions_tier = 0;
@@ -590,10 +629,24 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
         rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
     }
   }
+  if (rc == DPX_OK && h->regions_tier == 2) {
+    const char* nosplit = std::getenv("DPX_REGIONS_NOSPLIT");
+    h->regions_split = !(nosplit && nosplit[0] == '1');
+    if (h->regions_split) {
+      A(dev_alloc(&h->d_lds_img, B * (((h->lds2_bytes + 15) & ~size_t(15)) / 16)));
+      if (rc == DPX_OK && h->lds2_bytes > 48 * 1024) {
+        const int lb = static_cast<int>(h->lds2_bytes);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<true, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lb) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<true, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lb) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<true, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lb) != hipSuccess)
+          rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
+      }
+    }
+  }
   if (rc == DPX_OK && h->regions_tier > 0 && h->lds2_bytes > 48 * 1024) {
-    hipError_t e3 = h->regions_tier == 2 ? hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<true, false>),
+    hipError_t e3 = h->regions_tier == 2 ? hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<true, false, 0>),
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds2_bytes))
-                                         : hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<false, false>),
+                                         : hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<false, false, 0>),
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds2_bytes));
     if (e3 != hipSuccess) rc = fail(DPX_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e3));
   }
@@ -754,7 +807,7 @@ int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_
     DPX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_dbg), static_cast<size_t>(h->max_batch) * 16 * sizeof(unsigned long long)));
     DPX_HIP(hipMemset(h->d_dbg, 0, static_cast<size_t>(h->max_batch) * 16 * sizeof(unsigned long long)));
     if (h->lds2_bytes > 48 * 1024)
-      DPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds2_bytes)));
+      DPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<true, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds2_bytes)));
   }
   if (out16) {
     if (!h->d_dbg || frame < 0 || frame >= h->max_batch) return fail(DPX_ERR_ARG, "diagnostics not enabled or bad frame");
@@ -769,24 +822,38 @@ int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_
   return DPX_OK;
 }
 
-// ---- multi-stream pipeline: `depth` batches in flight, stages on dedicated streams -------------------------------
+// ---- streamed pipeline: `slots` groups of `group` batches in flight, one stream and one scratch set per slot ------
 struct dpx_pipeline_s {
   std::vector<dpx_handle> slots;
-  std::vector<hipStream_t> s_reg;
-  hipStream_t s_fit = nullptr, s_lab = nullptr;
+  std::vector<std::vector<SubBatch>> pending;  // per slot: submissions whose plane fit ran, region stage not yet
+  int group = 1, batch = 0;
   long long submitted = 0;
   int device = 0;
 };
 
+namespace {
+int pipeline_flush(dpx_pipeline p, size_t k) {
+  if (p->pending[k].empty()) return DPX_OK;
+  dpx_handle h = p->slots[k];
+  const int rc = stage_rest(h, p->pending[k].data(), static_cast<int>(p->pending[k].size()), p->batch, true, h->stream);
+  p->pending[k].clear();
+  return rc;
+}
+}  // namespace
+
 int dpx_pipeline_create(const dpx_config* cfg, int32_t image_height, int32_t image_width, int32_t batch, int32_t device,
-                        int32_t slots, int32_t region_streams, dpx_pipeline* out) {
-  if (!out || slots < 1 || region_streams < 0) return fail(DPX_ERR_ARG, "bad pipeline arguments");
+                        int32_t slots, int32_t group, dpx_pipeline* out) {
+  if (!out || slots < 1 || batch < 1) return fail(DPX_ERR_ARG, "bad pipeline arguments");
   *out = nullptr;
+  if (group < 1) group = 1;
+  if (group > 8) group = 8;
   dpx_pipeline p = new dpx_pipeline_s();
   p->device = device;
+  p->group = group;
+  p->batch = batch;
   for (int i = 0; i < slots; ++i) {
     dpx_handle h = nullptr;
-    const int rc = dpx_create(cfg, image_height, image_width, batch, device, &h);
+    const int rc = dpx_create(cfg, image_height, image_width, batch * group, device, &h);
     if (rc != DPX_OK) {
       const std::string keep = g_err;
       dpx_pipeline_destroy(p);
@@ -795,22 +862,7 @@ int dpx_pipeline_create(const dpx_config* cfg, int32_t image_height, int32_t ima
     }
     p->slots.push_back(h);
   }
-  // region_streams == 0 (default mode): every slot runs its three kernels on its own stream, no cross-stream events
-  // (hand-offs between streams cost ~20-30 us each on this stack, measured with tools/host_overhead.py);
-  // region_streams > 0: staged mode, plane fits / label expansions each serialised on one stream.
-  bool ok = true;
-  if (region_streams > 0)
-    ok = hipStreamCreateWithFlags(&p->s_fit, hipStreamNonBlocking) == hipSuccess &&
-         hipStreamCreateWithFlags(&p->s_lab, hipStreamNonBlocking) == hipSuccess;
-  for (int i = 0; ok && i < region_streams; ++i) {
-    hipStream_t s = nullptr;
-    ok = hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;
-    if (ok) p->s_reg.push_back(s);
-  }
-  if (!ok) {
-    dpx_pipeline_destroy(p);
-    return fail(DPX_ERR_HIP, "hipStreamCreate failed");
-  }
+  p->pending.resize(p->slots.size());
   *out = p;
   return DPX_OK;
 }
@@ -820,32 +872,34 @@ void dpx_pipeline_destroy(dpx_pipeline p) {
   (void)hipSetDevice(p->device);
   (void)hipDeviceSynchronize();
   for (auto h : p->slots) dpx_destroy(h);
-  if (p->s_fit) hipStreamDestroy(p->s_fit);
-  if (p->s_lab) hipStreamDestroy(p->s_lab);
-  for (auto s : p->s_reg) hipStreamDestroy(s);
   delete p;
 }
 
 int dpx_pipeline_submit_depth(dpx_pipeline p, const void* d_depth, int32_t batch, float fx, float fy, float cx, float cy,
                               void* d_labels) {
-  if (!p || (batch > 0 && (!d_depth || !d_labels))) return fail(DPX_ERR_ARG, "bad argument");
+  if (!p || !d_depth || !d_labels) return fail(DPX_ERR_ARG, "bad argument");
+  if (batch != p->batch) return fail(DPX_ERR_ARG, "pipeline submissions must have the batch size given at creation");
   const long long n = p->submitted++;
-  dpx_handle h = p->slots[n % p->slots.size()];
-  if (p->s_reg.empty()) return run_pipeline(h, d_depth, true, batch, fx, fy, cx, cy, static_cast<int32_t*>(d_labels), h->stream);
-  return run_pipeline3(h, d_depth, true, batch, fx, fy, cx, cy, static_cast<int32_t*>(d_labels), p->s_fit,
-                       p->s_reg[n % p->s_reg.size()], p->s_lab);
+  const size_t k = static_cast<size_t>((n / p->group) % static_cast<long long>(p->slots.size()));
+  const int j = static_cast<int>(n % p->group);
+  dpx_handle h = p->slots[k];
+  int rc = stage_fit(h, d_depth, true, batch, fx, fy, cx, cy, j * p->batch, h->stream);
+  if (rc) return rc;
+  p->pending[k].push_back(SubBatch{d_depth, static_cast<int32_t*>(d_labels)});
+  if (j == p->group - 1) rc = pipeline_flush(p, k);
+  return rc;
 }
 
 int dpx_pipeline_sync(dpx_pipeline p) {
   if (!p) return fail(DPX_ERR_ARG, "null pipeline");
   DPX_HIP(hipSetDevice(p->device));
-  if (p->s_reg.empty()) {
-    for (auto h : p->slots) DPX_HIP(hipStreamSynchronize(h->stream));
-    return DPX_OK;
+  for (size_t k = 0; k < p->slots.size(); ++k) {
+    const int rc = pipeline_flush(p, k);
+    if (rc) return rc;
   }
-  DPX_HIP(hipStreamSynchronize(p->s_fit));
-  for (auto s : p->s_reg) DPX_HIP(hipStreamSynchronize(s));
-  DPX_HIP(hipStreamSynchronize(p->s_lab));
+  // a partially filled group was flushed: the next submission starts a new group
+  p->submitted = ((p->submitted + p->group - 1) / p->group) * p->group;
+  for (auto h : p->slots) DPX_HIP(hipStreamSynchronize(h->stream));
   return DPX_OK;
 }
 
@@ -905,9 +959,9 @@ int dpx_time_planefit(dpx_handle h, const void* d_in, int32_t input_kind, int32_
   }
   for (int i = 0; i < iters; ++i) {
     if (input_kind == 0)
-      launch_planefit_depth(h, prm, d_in, s);
+      launch_planefit_depth(h, prm, d_in, h->d_cells, s);
     else
-      launch_planefit_cloud(h, prm, d_in, s);
+      launch_planefit_cloud(h, prm, d_in, h->d_cells, s);
   }
   DPX_HIP(hipEventRecord(b, s));
   DPX_HIP(hipEventSynchronize(b));

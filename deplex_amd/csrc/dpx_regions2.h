@@ -53,18 +53,31 @@ __device__ __forceinline__ uint32_t ordered_f32(float f) {
 #endif
 constexpr int kRT = DPX_RT;        // threads per frame workgroup
 constexpr int kRW = DPX_RT / 64;   // waves
+constexpr int kStage = 32;         // entries of the per-wave staging buffer of the accumulation phase
+constexpr int kStageFloats = (kRW * kStage * 9 > 2304) ? kRW * kStage * 9 : 2304;  // the merge phase needs 2304 words
 
 struct Regions2Extra {
   const float* mse_c;   // [B][C] compact per-cell mse (k_cellgraph output)
   uint32_t* cand_grow;  // [B][pcap] grow index of each candidate segment
   unsigned long long* dbg;  // diagnostic build only: [B][16] shader-clock stamps / sums
+  float4* lds_img;          // split mode: [B][img_bytes] image of the workgroup's LDS handed from phase to phase
+  int img_bytes;            // multiple of 16
+  int32_t* labels_out[8];   // non-null: the tail also expands the cell labels to the pixel label map (fused K6);
+  int frames_per_out;       // frame f writes to labels_out[f / frames_per_out] (grouped submissions have one buffer each)
 };
 
 #define DPX_STAMP() (DBG ? static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) : 0ull)
 
 // DBG = true is a separate diagnostic instantiation (phase timing through s_memtime); production uses DBG = false.
-template <bool FULL, bool DBG>
-__global__ __launch_bounds__(kRT) void k_regions2(Params prm, RegionBufs rb, Regions2Extra rx) {
+//
+// PHASE splits the kernel into three launches that hand the workgroup's LDS image over through global memory:
+//   1 = preparation (P0, kRT threads), 2 = seeds + region growing (P1, ONE wave per frame), 3 = the parallel tail
+//   (P2..P6, kRT threads); 0 = everything in one launch.  Why: the sequential phase takes ~85 % of the kernel's time but
+//   uses one wave; in a single launch the other waves of the workgroup sit at a barrier holding ~100 VGPRs each, and with
+//   16 batches in flight the resident region workgroups leave no registers / wave slots for the plane-fit kernel of the
+//   next batches (measured: its marginal cost doubles).  The one-wave launch needs ~1/8 of the registers and slots.
+template <bool FULL, bool DBG, int PHASE>
+__global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, RegionBufs rb, Regions2Extra rx) {
   unsigned long long t_start = DPX_STAMP(), t_p0 = 0, t_p1 = 0, t_p2 = 0, t_p3 = 0, t_p4 = 0, t_p5 = 0;
   unsigned long long a_argmax = 0, a_seed = 0, a_bfs = 0, a_rem = 0, n_steps = 0;
   const int frame = blockIdx.x;
@@ -76,15 +89,15 @@ __global__ __launch_bounds__(kRT) void k_regions2(Params prm, RegionBufs rb, Reg
   extern __shared__ __align__(16) unsigned char smem[];
   int* hdr = reinterpret_cast<int*>(smem);  // 48 ints: 0 planar count, 1 tail, 2 ngrow, 3 ncand, 5 nnz bins, 16.. wave counts
   int* hist = hdr + 48;
-  int* bin_start = hist + nb;        // nb + 1
-  int* cursor = bin_start + nb + 1;  // nb
-  float* stage = reinterpret_cast<float*>(cursor + nb);  // kRW waves x 64 entries x 9 floats (>= 2304 floats)
-  float* mse_l = stage + kRW * 64 * 9;                     // FULL: C floats
+  int* cursor = hist + nb;           // nb: fill cursor, then END of bin b's (compacted) cell list
+  float* stage = reinterpret_cast<float*>(cursor + nb);  // kRW waves x 32 entries x 9 floats (2304 floats for 8 waves)
+  float* mse_l = stage + kStageFloats;                     // FULL: C floats
   uint16_t* qpos = reinterpret_cast<uint16_t*>(mse_l + (FULL ? C : 0));
   uint16_t* queue = qpos + C;
   uint16_t* order = queue + C;
   uint16_t* binof = order + C;  // FULL: C (bin + 1)
-  uint8_t* flags = reinterpret_cast<uint8_t*>(binof + (FULL ? C : 0));
+  uint16_t* bin_start = binof + (FULL ? C : 0);  // nb + 1 (+1 pad): begin of bin b's cell list
+  uint8_t* flags = reinterpret_cast<uint8_t*>(bin_start + nb + 2);
   // (the list of non-empty bins lives in the first nb uint16 of `stage` during P1; stage is not used before P2)
   uint16_t* nzlist = reinterpret_cast<uint16_t*>(stage);
 
@@ -99,6 +112,14 @@ __global__ __launch_bounds__(kRT) void k_regions2(Params prm, RegionBufs rb, Reg
   uint2* pairs = rb.pairs + static_cast<size_t>(frame) * 2 * C;
   int32_t* merge = rb.merge + static_cast<size_t>(frame) * rb.pcap;
 
+  float4* lds_v = reinterpret_cast<float4*>(smem);
+  float4* img = rx.lds_img + static_cast<size_t>(frame) * (rx.img_bytes >> 4);
+  const int img_vec = rx.img_bytes >> 4;
+  if (PHASE >= 2) {  // continue from the previous launch's LDS image
+    for (int i = tid; i < img_vec; i += static_cast<int>(blockDim.x)) lds_v[i] = img[i];
+    __syncthreads();
+  }
+  if (PHASE <= 1) {
   // ---------------- P0: state into LDS, histogram, bin-grouped order ------------------------------------
   for (int b = tid; b < nb; b += kRT) hist[b] = 0;
   if (tid < 48) hdr[tid] = 0;
@@ -162,7 +183,7 @@ __global__ __launch_bounds__(kRT) void k_regions2(Params prm, RegionBufs rb, Reg
       const int v = b < nb ? hist[b] : 0;
       const int incl = wave_incl_scan(v, lane);
       if (b < nb) {
-        bin_start[b] = carry + incl - v;
+        bin_start[b] = static_cast<uint16_t>(carry + incl - v);
         cursor[b] = carry + incl - v;
       }
       carry += __shfl(incl, 63);
@@ -172,7 +193,7 @@ __global__ __launch_bounds__(kRT) void k_regions2(Params prm, RegionBufs rb, Reg
       if (lane == 0) hdr[5] += __popcll(nzm);
       wave_sync();
     }
-    if (lane == 0) bin_start[nb] = carry;
+    if (lane == 0) bin_start[nb] = static_cast<uint16_t>(carry);
   }
   __syncthreads();
   for (int c = tid; c < C; c += kRT) {
@@ -183,12 +204,17 @@ __global__ __launch_bounds__(kRT) void k_regions2(Params prm, RegionBufs rb, Reg
     }
   }
   __syncthreads();
+  }  // PHASE <= 1
+  if (PHASE == 1) {
+    for (int i = tid; i < img_vec; i += static_cast<int>(blockDim.x)) img[i] = lds_v[i];
+    return;
+  }
   const int planar_total = hdr[0];
   t_p0 = DPX_STAMP();
 
   // ---------------- P1: seeds + region growing, wave 0 only ---------------------------------------------
   // cursor[b] now holds the END of bin b's (compacted) cell list; bin_start[b] its begin.
-  if (wid == 0) {
+  if ((PHASE == 0 || PHASE == 2) && wid == 0) {
     int remaining = planar_total;
     int tail = 0, ngrow = 0, ncand = 0;
     const int nnz = hdr[5];
@@ -326,6 +352,10 @@ __global__ __launch_bounds__(kRT) void k_regions2(Params prm, RegionBufs rb, Reg
     }
   }
   __syncthreads();
+  if (PHASE == 2) {
+    for (int i = tid; i < img_vec; i += static_cast<int>(blockDim.x)) img[i] = lds_v[i];
+    return;
+  }
   const int activations = hdr[1], ngrow = hdr[2], ncand = hdr[3];
   t_p1 = DPX_STAMP();
 
@@ -334,15 +364,15 @@ __global__ __launch_bounds__(kRT) void k_regions2(Params prm, RegionBufs rb, Reg
   for (int c = tid; c < C; c += kRT) lab16[c] = 0;
   // ---------------- P2: exact float accumulation of every candidate segment (wave per segment) ------------
   {
-    float* st = stage + wid * 64 * 9;
+    float* st = stage + wid * kStage * 9;
     const float4* cf4 = reinterpret_cast<const float4*>(cells);
     for (int ci = wid; ci < ncand; ci += kRW) {
       const int gi = static_cast<int>(cand_grow[ci]);
       const int gs = static_cast<int>(grow_start[gi]), ge = static_cast<int>(grow_start[gi + 1]);
       const int comp = lane < 9 ? lane : 0;
       float acc = reinterpret_cast<const float*>(cells)[static_cast<size_t>(queue[gs]) * 16 + comp];  // the seed, counted twice
-      for (int base = gs; base < ge; base += 64) {
-        const int cnt = (ge - base) < 64 ? (ge - base) : 64;
+      for (int base = gs; base < ge; base += kStage) {
+        const int cnt = (ge - base) < kStage ? (ge - base) : kStage;
         if (lane < cnt) {
           const size_t v = queue[base + lane];
           const float4 a = cf4[v * 4 + 0], b4 = cf4[v * 4 + 1], c4 = cf4[v * 4 + 2];
@@ -585,10 +615,40 @@ __global__ __launch_bounds__(kRT) void k_regions2(Params prm, RegionBufs rb, Reg
   // ---------------- P6: merged label per cell (toImageLabels' lookup, plane_extractor.cpp:464-465); records --------
   for (int c = tid; c < C; c += kRT) {
     const int L = lab16[c];
-    cell_labels[c] = (L == 0 || nplanes == 0) ? 0 : merge[L - 1] + 1;
+    const int fin = (L == 0 || nplanes == 0) ? 0 : merge[L - 1] + 1;
+    cell_labels[c] = fin;
+    lab16[c] = static_cast<uint16_t>(fin);  // final labels stay in LDS for the fused expansion below
   }
   if (nplanes > 0)
     for (int i = tid; i < nplanes; i += kRT) planes[i].merge_label = merge[i];
+  if (rx.labels_out[0]) {
+    // Fused toImageLabels (plane_extractor.cpp:455-470), W % 4 == 0: this workgroup writes its frame's label map with
+    // 16-byte stores straight from the LDS-resident cell labels.  Done here (on the few CUs that run region growing,
+    // in the background of the other batches' kernels) it removes a chip-wide launch from every batch.
+    __syncthreads();
+    const int sub = frame / rx.frames_per_out;
+    int32_t* outp = rx.labels_out[sub] + static_cast<size_t>(frame - sub * rx.frames_per_out) * prm.N;
+    const int W4 = prm.W >> 2, P = prm.P;
+    const int total = prm.H * W4;
+    for (int idx = tid; idx < total; idx += kRT) {
+      const int row = idx / W4, q = idx - row * W4;
+      const int col = q << 2;
+      const int cr = row / P;
+      int cc = col / P;
+      int rem = col - cc * P;
+      int4 v;
+      int32_t* vp = reinterpret_cast<int32_t*>(&v);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        vp[i] = (cr < nv && cc < nh) ? static_cast<int32_t>(lab16[cr * nh + cc]) : 0;
+        if (++rem == P) {
+          rem = 0;
+          ++cc;
+        }
+      }
+      *reinterpret_cast<int4*>(outp + static_cast<size_t>(row) * prm.W + col) = v;
+    }
+  }
   if (tid == 0) {
     dpx_frame_stats st;
     st.planar_cells = planar_total;

@@ -190,16 +190,17 @@ class PlaneExtractor:
 
 class Pipeline:
     """Streamed, pipelined processing of depth batches that already live in device memory (dpx_pipeline_*):
-    `slots` batches in flight, one stream per slot (region_streams=0) so the latency-bound region growing of one batch
-    overlaps the other batches' plane fits and label expansions; region_streams>0 selects the staged mode."""
+    `slots` groups of `group` submissions in flight, one stream per slot; plane fits run per submission, region growing
+    and label expansion once per group.  Results are complete after sync()."""
 
     def __init__(self, image_height: int, image_width: int, config: Optional[Config] = None, *, batch: int = 64,
-                 slots: int = 16, region_streams: int = 0, device: int = 0):
+                 slots: int = 16, group: int = 1, device: int = 0):
         self._p = C.c_void_p()
         cfg = config if config is not None else Config()
         self.image_height, self.image_width, self.batch, self.slots = int(image_height), int(image_width), int(batch), int(slots)
+        self.group = max(1, min(8, int(group)))
         _capi.check(_capi.lib().dpx_pipeline_create(C.byref(cfg._c), self.image_height, self.image_width, self.batch,
-                                                   int(device), self.slots, int(region_streams), C.byref(self._p)))
+                                                   int(device), self.slots, int(group), C.byref(self._p)))
 
     def submit_depth(self, d_depth_ptr: int, batch: int, fx, fy, cx, cy, d_labels_ptr: int) -> None:
         _capi.check(_capi.lib().dpx_pipeline_submit_depth(self._p, d_depth_ptr, batch, fx, fy, cx, cy, d_labels_ptr))
@@ -214,7 +215,7 @@ class Pipeline:
             raise IndexError(k)
         ex = PlaneExtractor.__new__(PlaneExtractor)
         ex._h = C.c_void_p(h)
-        ex.image_height, ex.image_width, ex.max_batch = self.image_height, self.image_width, self.batch
+        ex.image_height, ex.image_width, ex.max_batch = self.image_height, self.image_width, self.batch * self.group
         nh, nv = C.c_int32(), C.c_int32()
         _capi.check(_capi.lib().dpx_grid_dims(ex._h, C.byref(nh), C.byref(nv)))
         ex.nh, ex.nv = nh.value, nv.value

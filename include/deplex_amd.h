@@ -132,16 +132,16 @@ int dpx_process_depth_batch_device(dpx_handle h, const void* d_depth, int32_t ba
                                    float cy, void* d_labels, void* hip_stream);
 int dpx_process_pcd_batch_device(dpx_handle h, const void* d_xyz, int32_t batch, void* d_labels, void* hip_stream);
 
-/* Streamed processing (the reference's examples/process_sequence.cpp:30-53 loop, pipelined): `slots` batches in
- * flight, each with its own scratch and — with region_streams == 0, the default mode — its own stream, so the
- * latency-bound region growing of one batch overlaps the plane fits and label expansions of the others.
- * region_streams > 0 selects a staged mode (plane fits serialised on one stream, label expansions on another, region
- * growing on `region_streams` streams, hand-offs through events); it is slower on ROCm 7.2 and kept for comparison.
- * submit() is asynchronous on device pointers; the caller must not reuse d_depth / d_labels of a submission before
- * dpx_pipeline_sync() (or `slots` later submissions) completed.  dpx_pipeline_slot() exposes the per-slot handle
- * for the result getters and profiling. */
+/* Streamed processing (the reference's examples/process_sequence.cpp:30-53 loop, pipelined).  `slots` groups of
+ * `group` (1..8) submissions are in flight, each slot with its own scratch and stream.  Every submission's plane fit is
+ * launched at once; region growing + label expansion run once per group, for all its frames in one launch (the GPU
+ * executes only a handful of kernels concurrently, so one latency-bound region launch per small batch wastes those
+ * slots; group = 1 restores launch-per-submission).  Submissions must all have the batch size given at creation.
+ * submit() is asynchronous on device pointers; results of a submission are complete after dpx_pipeline_sync() (which
+ * also flushes a partially filled group).  The caller must not reuse d_depth / d_labels of a submission before that.
+ * dpx_pipeline_slot() exposes the per-slot handle (frames of a slot = its group's submissions back to back). */
 int dpx_pipeline_create(const dpx_config* cfg, int32_t image_height, int32_t image_width, int32_t batch, int32_t device,
-                        int32_t slots, int32_t region_streams, dpx_pipeline* out);
+                        int32_t slots, int32_t group, dpx_pipeline* out);
 void dpx_pipeline_destroy(dpx_pipeline p);
 int dpx_pipeline_submit_depth(dpx_pipeline p, const void* d_depth, int32_t batch, float fx, float fy, float cx, float cy,
                               void* d_labels);

@@ -204,7 +204,7 @@ def test_ragged_and_tiny_images(D, oracle):
         full_compare(D, oracle, depth, synth.intrinsics_for(h, w), oracle.default_config())
 
 
-@pytest.mark.parametrize("env", ["DPX_FORCE_GLOBAL_STATE", "DPX_REGIONS_V1", "DPX_REGIONS_LEAN", "DPX_NO_FASTDIV", "DPX_PLANEFIT_V1", "DPX_LABELS_V1"])
+@pytest.mark.parametrize("env", ["DPX_FORCE_GLOBAL_STATE", "DPX_REGIONS_V1", "DPX_REGIONS_LEAN", "DPX_NO_FASTDIV", "DPX_PLANEFIT_V1", "DPX_LABELS_V1", "DPX_REGIONS_NOSPLIT", "DPX_NO_FUSED_LABELS"])
 def test_kernel_variants(D, oracle, env):
     """Every kernel variant must give the same bits: region growing with its per-cell state in global memory
     (used when a frame does not fit LDS), the v1 single-wave kernel, the lean LDS tier (mse/bin read from global),
@@ -343,8 +343,8 @@ def test_device_pointer_api_with_torch(D, oracle):
 
 
 def test_multistream_pipeline(D, oracle):
-    """dpx_pipeline: several batches in flight on separate plane-fit / region / label streams give the same bits as
-    the single-stream path, including when scratch slots are reused."""
+    """dpx_pipeline: several groups of batches in flight (one stream per slot, region growing once per group) give the
+    same bits as the single-stream path, including when scratch slots are reused and the last group is partial."""
     import torch
     h, w, B, steps = 240, 320, 4, 7
     intr = synth.intrinsics_for(h, w)
@@ -354,10 +354,10 @@ def test_multistream_pipeline(D, oracle):
     d_out = [torch.full((B, h * w), -1, dtype=torch.int32, device=dev) for _ in range(steps)]
     oracle.set_math("devmath")
     refs = [oracle.process_depth_batch(oracle.default_config(), b, *intr, threads=2) for b in batches]
-    for region_streams in (0, 2):  # per-slot streams (default) and the staged mode
+    for group in (1, 2, 3):  # launch per submission, and grouped region launches (7 steps: last group is partial)
         for o in d_out:
             o.fill_(-1)
-        pipe = D.Pipeline(h, w, D.Config(), batch=B, slots=3, region_streams=region_streams)
+        pipe = D.Pipeline(h, w, D.Config(), batch=B, slots=3, group=group)
         for k in range(3):
             pipe.slot(k).set_profiling(True)
         torch.cuda.synchronize()
@@ -365,10 +365,20 @@ def test_multistream_pipeline(D, oracle):
             pipe.submit_depth(d_in[i].data_ptr(), B, *intr, d_out[i].data_ptr())
         pipe.sync()
         for i in range(steps):
-            assert np.array_equal(d_out[i].cpu().numpy(), refs[i]), f"mode {region_streams} batch {i}"
+            assert np.array_equal(d_out[i].cpu().numpy(), refs[i]), f"group {group} batch {i}"
         ms = pipe.slot(0).kernel_ms()
         assert ms["planefit"] > 0 and ms["regions"] > 0 and ms["labels"] > 0
-        assert pipe.slot((steps - 1) % 3).frame_stats(0)["segments"] >= 0
+        assert pipe.slot(((steps - 1) // group) % 3).frame_stats(0)["segments"] >= 0
+        # a second round after the flush starts a fresh group
+        for o in d_out[:2]:
+            o.fill_(-1)
+        for i in range(2):
+            pipe.submit_depth(d_in[i].data_ptr(), B, *intr, d_out[i].data_ptr())
+        pipe.sync()
+        for i in range(2):
+            assert np.array_equal(d_out[i].cpu().numpy(), refs[i]), f"group {group} second round batch {i}"
+        with pytest.raises(RuntimeError):
+            pipe.submit_depth(d_in[0].data_ptr(), B - 1, *intr, d_out[0].data_ptr())
         del pipe
 
 

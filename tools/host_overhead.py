@@ -12,7 +12,7 @@ K = synth.read_K(synth.TUM_K); intr = tuple(float(v) for v in (K[0, 0], K[1, 1],
 dev = torch.device("cuda", 0)
 d = torch.from_numpy(depth.view(np.int16)).to(dev)
 S = 16
-lab = torch.empty((S, B, 480 * 640), dtype=torch.int32, device=dev)
+lab = torch.empty((S * 4, B, 480 * 640), dtype=torch.int32, device=dev)
 def run(name, submit, sync, n=256):
     for i in range(32): submit(i)
     sync()
@@ -26,10 +26,10 @@ for prof in (False, True):
     exs = [D.PlaneExtractor(480, 640, max_batch=B) for _ in range(S)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     for e in exs: e.prepare_intrinsics(*intr); e.set_profiling(prof)
-    run(f"handles x{S} prof={prof}", lambda i: exs[i % S].process_depth_device(d.data_ptr(), B, *intr, lab[i % S].data_ptr(), streams[i % S].cuda_stream), lambda: torch.cuda.synchronize())
+    run(f"handles x{S} prof={prof}", lambda i: exs[i % S].process_depth_device(d.data_ptr(), B, *intr, lab[i % len(lab)].data_ptr(), streams[i % S].cuda_stream), lambda: torch.cuda.synchronize())
     del exs
-    for rs in (12, 4):
-        pipe = D.Pipeline(480, 640, batch=B, slots=S, region_streams=rs)
+    for rs in (1, 4):
+        pipe = D.Pipeline(480, 640, batch=B, slots=S, group=rs)
         for k in range(S): pipe.slot(k).prepare_intrinsics(*intr); pipe.slot(k).set_profiling(prof)
-        run(f"pipeline slots={S} rs={rs} prof={prof}", lambda i: pipe.submit_depth(d.data_ptr(), B, *intr, lab[i % S].data_ptr()), lambda: (pipe.sync(), torch.cuda.synchronize()))
+        run(f"pipeline slots={S} group={rs} prof={prof}", lambda i: pipe.submit_depth(d.data_ptr(), B, *intr, lab[i % len(lab)].data_ptr()), lambda: (pipe.sync(), torch.cuda.synchronize()))
         del pipe
