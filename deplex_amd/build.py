@@ -16,7 +16,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared"
 
 
 def sources():
-    return [SRC / "dpx_api.hip", SRC / "dpx_kernels.h", SRC / "dpx_regions.h", SRC / "dpx_regions2.h", SRC / "dpx_refine.h", SRC / "dpx_planefit_fast.h", SRC / "dpx_fit.h", SRC / "dpx_math.h",
+    return [SRC / "dpx_api.hip", SRC / "dpx_kernels.h", SRC / "dpx_regions.h", SRC / "dpx_regions2.h", SRC / "dpx_binsort.h", SRC / "dpx_refine.h", SRC / "dpx_planefit_fast.h", SRC / "dpx_fit.h", SRC / "dpx_math.h",
             PKG.parent / "include" / "deplex_amd.h"]
 
 

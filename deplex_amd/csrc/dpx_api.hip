@@ -16,6 +16,7 @@
 #include "dpx_planefit_fast.h"
 #include "dpx_regions.h"
 #include "dpx_regions2.h"
+#include "dpx_binsort.h"
 #include "dpx_refine.h"
 
 namespace {
@@ -66,8 +67,15 @@ struct dpx_handle_s {
   bool regions_split = false;
   float* d_mse_c = nullptr;
   uint32_t* d_cand_grow = nullptr;
-  int regions_tier = 0;  // 2 = k_regions2<FULL>, 1 = k_regions2<LEAN>, 0 = k_regions (v1)
+  int regions_tier = -1;  // k_regions2<TIER>: 2 all state in LDS, 1 lean, 0 flags in LDS + global queues; -1 = k_regions (v1)
   size_t lds2_bytes = 0;
+  // variant switches, read from the environment at create (tests and diagnostics)
+  bool opt_nofuse = false, opt_labels_v1 = false;
+  int opt_csr_chunk = 64;
+  int Cpad = 0;                              // tiers 1/0: sort slots per frame (power of two >= C)
+  unsigned long long* d_sort_keys = nullptr;  // [B][Cpad]
+  uint32_t* d_bin_off = nullptr;              // [B][nb + 1]
+  uint32_t* d_gqpos = nullptr;                // tier 0: [B][C]
   uint8_t* d_gflags = nullptr;
   uint8_t* d_gowner = nullptr;
   uint32_t* d_gqueue = nullptr;
@@ -119,6 +127,9 @@ void free_all(dpx_handle h) {
   hipFree(h->d_gflags);
   hipFree(h->d_gowner);
   hipFree(h->d_gqueue);
+  hipFree(h->d_sort_keys);
+  hipFree(h->d_bin_off);
+  hipFree(h->d_gqpos);
   hipFree(h->d_in);
   hipFree(h->d_labels);
   hipFree(h->d_mismatch);
@@ -227,6 +238,24 @@ struct SubBatch {
   int32_t* d_labels;
 };
 
+// seed lists of the sorted region tiers (dpx_binsort.h): keys -> bitonic network -> per-bin cell lists
+void launch_binsort(dpx_handle h, const dpx::Params& prm, hipStream_t s) {
+  const int Cpad = h->Cpad, B = prm.batch;
+  const long long slots = static_cast<long long>(B) * Cpad;
+  const unsigned g256 = static_cast<unsigned>((slots + 255) / 256);
+  hipLaunchKernelGGL(dpx::k_sort_build, dim3(g256), dim3(256), 0, s, prm, h->d_meta, h->d_mse_c, h->d_sort_keys, Cpad);
+  const int tile = Cpad < dpx::kSortTile ? Cpad : dpx::kSortTile;
+  const unsigned tiles = static_cast<unsigned>(slots / tile);
+  const size_t lds = static_cast<size_t>(tile) * 8;
+  hipLaunchKernelGGL(dpx::k_sort_tile, dim3(tiles), dim3(dpx::kSortThreads), lds, s, h->d_sort_keys, Cpad, tile, 2);
+  for (int k = tile * 2; k <= Cpad; k <<= 1) {
+    for (int j = k >> 1; j >= tile; j >>= 1)
+      hipLaunchKernelGGL(dpx::k_sort_global, dim3(static_cast<unsigned>((slots / 2 + 255) / 256)), dim3(256), 0, s, h->d_sort_keys, Cpad, B, j, k);
+    hipLaunchKernelGGL(dpx::k_sort_tile, dim3(tiles), dim3(dpx::kSortThreads), lds, s, h->d_sort_keys, Cpad, tile, k);
+  }
+  hipLaunchKernelGGL(dpx::k_sort_lists, dim3(g256), dim3(256), 0, s, prm, h->d_sort_keys, Cpad, h->d_order, h->d_bin_off);
+}
+
 int stage_fit(dpx_handle h, const void* d_in, bool depth, int batch, float fx, float fy, float cx, float cy, int frame_off,
               hipStream_t s) {
   if (batch < 0 || frame_off < 0 || frame_off + batch > h->max_batch)
@@ -277,6 +306,7 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   const long long total = static_cast<long long>(batch) * prm.C;
   if (total > 0 && h->regions_tier != 2)
     hipLaunchKernelGGL(dpx::k_cellgraph, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, prm, h->d_cells, h->d_meta, h->d_mse_c);
+  if (total > 0 && (h->regions_tier == 1 || h->regions_tier == 0) && !skip_r) launch_binsort(h, prm, s);
   if (prof) DPX_HIP(hipEventRecord(ev[3], s));
   dpx::RegionBufs rb{};
   rb.cells = h->d_cells; rb.meta = h->d_meta; rb.order = h->d_order; rb.grow_start = h->d_grow_start;
@@ -284,24 +314,32 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   rb.merge = h->d_merge; rb.stats = h->d_stats; rb.g_flags = h->d_gflags; rb.g_owner = h->d_gowner;
   rb.g_queue = h->d_gqueue; rb.pcap = h->pcap;
   // the region kernel's tail can write the pixel label map itself (no separate label-expansion launch)
-  static const bool nofuse = std::getenv("DPX_NO_FUSED_LABELS") != nullptr;
-  const bool fuse_labels = h->regions_tier == 2 && (prm.W & 3) == 0 && !nofuse && !skip_l && !skip_r;
+  const bool fuse_labels = h->regions_tier == 2 && (prm.W & 3) == 0 && !h->opt_nofuse && !skip_l && !skip_r;
   dpx::Regions2Extra rx{};
   rx.mse_c = h->d_mse_c; rx.cand_grow = h->d_cand_grow; rx.dbg = h->d_dbg; rx.lds_img = h->d_lds_img;
   rx.img_bytes = static_cast<int>((h->lds2_bytes + 15) & ~size_t(15));
+  rx.csr_chunk = h->opt_csr_chunk;
+  rx.bin_off = h->d_bin_off;
+  rx.g_qpos = h->d_gqpos;
   rx.frames_per_out = per_sub;
   for (int j = 0; j < 8; ++j) rx.labels_out[j] = (fuse_labels && j < nsub) ? subs[j].d_labels : nullptr;
   if (skip_r) {
   } else if (h->regions_tier == 2 && h->d_dbg)
-    hipLaunchKernelGGL((dpx::k_regions2<true, true, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<2, true, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
+  else if (h->regions_tier == 1 && h->d_dbg)
+    hipLaunchKernelGGL((dpx::k_regions2<1, true, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
+  else if (h->regions_tier == 0 && h->d_dbg)
+    hipLaunchKernelGGL((dpx::k_regions2<0, true, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
   else if (h->regions_tier == 2 && h->regions_split) {
-    hipLaunchKernelGGL((dpx::k_regions2<true, false, 1>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
-    hipLaunchKernelGGL((dpx::k_regions2<true, false, 2>), dim3(batch), dim3(64), h->lds2_bytes, s, prm, rb, rx);
-    hipLaunchKernelGGL((dpx::k_regions2<true, false, 3>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<2, false, 1>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<2, false, 2>), dim3(batch), dim3(64), h->lds2_bytes, s, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<2, false, 3>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
   } else if (h->regions_tier == 2)
-    hipLaunchKernelGGL((dpx::k_regions2<true, false, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<2, false, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
   else if (h->regions_tier == 1)
-    hipLaunchKernelGGL((dpx::k_regions2<false, false, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<1, false, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
+  else if (h->regions_tier == 0)
+    hipLaunchKernelGGL((dpx::k_regions2<0, false, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
   else if (h->use_lds)
     hipLaunchKernelGGL(dpx::k_regions<true>, dim3(batch), dim3(64), h->lds_bytes, s, prm, rb);
   else
@@ -310,7 +348,7 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   // ---- label expansion (per sub-batch: each has its own output buffer)
   if (prof) DPX_HIP(hipEventRecord(ev[5], s));
   if (!skip_l && !fuse_labels) {
-    static const bool labels_v1 = std::getenv("DPX_LABELS_V1") != nullptr;
+    const bool labels_v1 = h->opt_labels_v1;
     dpx::Params ps = prm;
     ps.batch = per_sub;
     for (int j = 0; j < nsub; ++j) {
@@ -564,6 +602,12 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
   }
   const size_t C = static_cast<size_t>(p.C);
   const size_t lds_state = hist_bytes + 6 * C + 16;
+  h->opt_nofuse = std::getenv("DPX_NO_FUSED_LABELS") != nullptr;
+  h->opt_labels_v1 = std::getenv("DPX_LABELS_V1") != nullptr;
+  if (const char* e = std::getenv("DPX_CSR_CHUNK")) {  // test hook: force the wide-row walk of the merge phase
+    const int v = std::atoi(e);
+    h->opt_csr_chunk = v < 0 ? 0 : (v > 64 ? 64 : v);
+  }
   const char* force = std::getenv("DPX_FORCE_GLOBAL_STATE");
   h->use_lds = lds_state <= kLdsLimit && !(force && force[0] == '1');
   h->lds_bytes = h->use_lds ? lds_state : hist_bytes + 16;
@@ -571,19 +615,30 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
                                                       ? static_cast<long long>(C)
                                                       : static_cast<long long>(C) / cfg->min_region_growing_cells_activated));
   {
-    // region-growing kernel tier: everything in LDS (13 B/cell), lean (7 B/cell), or the v1 kernel
+    // region-growing kernel tier: everything in LDS (13 B/cell), lean (7 B/cell), flag byte only (1 B/cell, queues in
+    // global memory), or the v1 kernel
     const size_t fixed = 192 + static_cast<size_t>(2 * nb) * 4 + static_cast<size_t>(nb + 2) * 2 + static_cast<size_t>(dpx::kStageFloats) * 4 + 16;
+    const size_t fixed0 = 192 + static_cast<size_t>(2 * nb) * 4 + static_cast<size_t>(nb + 2) * 4 + static_cast<size_t>(dpx::kStageFloats) * 4 + 16;
     const char* v1 = std::getenv("DPX_REGIONS_V1");
     const char* lean = std::getenv("DPX_REGIONS_LEAN");
-    h->regions_tier = 0;
-    if (!(v1 && v1[0] == '1') && !(force && force[0] == '1') && C < 65000 && nb < 4600) {
-      if (fixed + 13 * C <= kLdsLimit && !(lean && lean[0] == '1')) {
+    const char* gst = std::getenv("DPX_REGIONS_GSTATE");
+    const bool want_lean = lean && lean[0] == '1', want_gst = gst && gst[0] == '1';
+    h->regions_tier = -1;
+    if (!(v1 && v1[0] == '1') && !(force && force[0] == '1') && nb < 4600) {
+      if (C < 65000 && fixed + 13 * C <= kLdsLimit && !want_lean && !want_gst) {
         h->regions_tier = 2;
         h->lds2_bytes = fixed + 13 * C;
-      } else if (fixed + 7 * C <= kLdsLimit) {
+      } else if (C < 65000 && fixed + 7 * C <= kLdsLimit && !want_gst) {
         h->regions_tier = 1;
         h->lds2_bytes = fixed + 7 * C;
+      } else if (C < (size_t(1) << dpx::kKeyCellBits) && fixed0 + C <= kLdsLimit) {
+        h->regions_tier = 0;
+        h->lds2_bytes = fixed0 + C;
       }
+    }
+    if (h->regions_tier == 1 || h->regions_tier == 0) {
+      h->Cpad = 1;
+      while (static_cast<size_t>(h->Cpad) < C) h->Cpad <<= 1;
     }
   }
   const size_t B = static_cast<size_t>(max_batch);
@@ -601,9 +656,17 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
   A(dev_alloc(&h->d_stats, B));
   A(dev_alloc(&h->d_mse_c, B * C));
   A(dev_alloc(&h->d_cand_grow, B * h->pcap));
-  if (!h->use_lds) {
+  if (!h->use_lds && h->regions_tier < 0) {
     A(dev_alloc(&h->d_gflags, B * C));
     A(dev_alloc(&h->d_gowner, B * C));
+    A(dev_alloc(&h->d_gqueue, B * C));
+  }
+  if (h->regions_tier == 1 || h->regions_tier == 0) {
+    A(dev_alloc(&h->d_sort_keys, B * static_cast<size_t>(h->Cpad)));
+    A(dev_alloc(&h->d_bin_off, B * static_cast<size_t>(nb + 1)));
+  }
+  if (h->regions_tier == 0) {
+    A(dev_alloc(&h->d_gqpos, B * C));
     A(dev_alloc(&h->d_gqueue, B * C));
   }
   if (rc == DPX_OK && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
@@ -636,18 +699,18 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
       A(dev_alloc(&h->d_lds_img, B * (((h->lds2_bytes + 15) & ~size_t(15)) / 16)));
       if (rc == DPX_OK && h->lds2_bytes > 48 * 1024) {
         const int lb = static_cast<int>(h->lds2_bytes);
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<true, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lb) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<true, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lb) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<true, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lb) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<2, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lb) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<2, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lb) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<2, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lb) != hipSuccess)
           rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
       }
     }
   }
-  if (rc == DPX_OK && h->regions_tier > 0 && h->lds2_bytes > 48 * 1024) {
-    hipError_t e3 = h->regions_tier == 2 ? hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<true, false, 0>),
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds2_bytes))
-                                         : hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<false, false, 0>),
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds2_bytes));
+  if (rc == DPX_OK && h->regions_tier >= 0 && h->lds2_bytes > 48 * 1024) {
+    const void* fn = h->regions_tier == 2   ? reinterpret_cast<const void*>(dpx::k_regions2<2, false, 0>)
+                     : h->regions_tier == 1 ? reinterpret_cast<const void*>(dpx::k_regions2<1, false, 0>)
+                                            : reinterpret_cast<const void*>(dpx::k_regions2<0, false, 0>);
+    hipError_t e3 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds2_bytes));
     if (e3 != hipSuccess) rc = fail(DPX_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e3));
   }
   if (rc != DPX_OK) {
@@ -806,8 +869,12 @@ int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_
   if (enable && !h->d_dbg) {
     DPX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_dbg), static_cast<size_t>(h->max_batch) * 16 * sizeof(unsigned long long)));
     DPX_HIP(hipMemset(h->d_dbg, 0, static_cast<size_t>(h->max_batch) * 16 * sizeof(unsigned long long)));
-    if (h->lds2_bytes > 48 * 1024)
-      DPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<true, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds2_bytes)));
+    if (h->lds2_bytes > 48 * 1024 && h->regions_tier >= 0) {
+      const void* fn = h->regions_tier == 2   ? reinterpret_cast<const void*>(dpx::k_regions2<2, true, 0>)
+                       : h->regions_tier == 1 ? reinterpret_cast<const void*>(dpx::k_regions2<1, true, 0>)
+                                              : reinterpret_cast<const void*>(dpx::k_regions2<0, true, 0>);
+      DPX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds2_bytes)));
+    }
   }
   if (out16) {
     if (!h->d_dbg || frame < 0 || frame >= h->max_batch) return fail(DPX_ERR_ARG, "diagnostics not enabled or bad frame");
@@ -816,7 +883,6 @@ int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_
   }
   if (!enable && h->d_dbg) {
     hipFree(h->d_dbg);
-  hipFree(h->d_mt_init);
     h->d_dbg = nullptr;
   }
   return DPX_OK;

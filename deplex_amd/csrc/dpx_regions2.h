@@ -15,6 +15,8 @@
 //     all four waves; the inherently sequential seed loop runs on wave 0 while the others wait at the barrier.
 // Reference: plane_extractor.cpp:297-453, normals_histogram.cpp:51-72 (see dpx_regions.h for the parity notes).
 #pragma once
+#include <type_traits>
+
 #include "dpx_regions.h"
 
 namespace dpx {
@@ -62,6 +64,9 @@ struct Regions2Extra {
   unsigned long long* dbg;  // diagnostic build only: [B][16] shader-clock stamps / sums
   float4* lds_img;          // split mode: [B][img_bytes] image of the workgroup's LDS handed from phase to phase
   int img_bytes;            // multiple of 16
+  const uint32_t* bin_off;  // sorted tiers: [B][nb + 1] offsets of each bin's list inside rb.order (dpx_binsort.h)
+  uint32_t* g_qpos;         // tier 0: [B][C] queue position of each cell
+  int csr_chunk;            // merge phase: rows with more adjacency entries than this (<= 64) use the bit-row walk
   int32_t* labels_out[8];   // non-null: the tail also expands the cell labels to the pixel label map (fused K6);
   int frames_per_out;       // frame f writes to labels_out[f / frames_per_out] (grouped submissions have one buffer each)
 };
@@ -76,8 +81,25 @@ struct Regions2Extra {
 //   uses one wave; in a single launch the other waves of the workgroup sit at a barrier holding ~100 VGPRs each, and with
 //   16 batches in flight the resident region workgroups leave no registers / wave slots for the plane-fit kernel of the
 //   next batches (measured: its marginal cost doubles).  The one-wave launch needs ~1/8 of the registers and slots.
-template <bool FULL, bool DBG, int PHASE>
+#ifndef DPX_REGIONS_PRIO
+#define DPX_REGIONS_PRIO 3
+#endif
+// TIER: where the per-cell state of the sequential phase lives
+//   2 = everything in LDS (13 B/cell), cell graph fused in, seed = scan of the bin's (unsorted) list;
+//   1 = flags, queue, queue positions and the SORTED seed lists in LDS (7 B/cell); bins via the cell-graph words;
+//   0 = only the flag byte in LDS; queue, queue positions and sorted seed lists in global memory (L2) with 32-bit
+//       indices — frames up to ~150 000 cells (3840x2160 at P = 10 has 82 944).
+// Tiers 1 and 0 take their seed lists from dpx_binsort.h (rb.order + rx.bin_off).
+template <int TIER, bool DBG, int PHASE>
 __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, RegionBufs rb, Regions2Extra rx) {
+  constexpr bool FULL = TIER == 2;
+  constexpr bool GST = TIER == 0;
+  using idx_t = typename std::conditional<GST, uint32_t, uint16_t>::type;
+  constexpr uint32_t kNoPos = GST ? 0xFFFFFFFFu : 0xFFFFu;
+  static_assert(PHASE == 0 || TIER == 2, "the phase-split launches exist for the all-LDS tier only");
+#if DPX_REGIONS_PRIO
+  __builtin_amdgcn_s_setprio(DPX_REGIONS_PRIO);  // latency-bound waves: win issue arbitration against co-resident streaming kernels
+#endif
   unsigned long long t_start = DPX_STAMP(), t_p0 = 0, t_p1 = 0, t_p2 = 0, t_p3 = 0, t_p4 = 0, t_p5 = 0;
   unsigned long long a_argmax = 0, a_seed = 0, a_bfs = 0, a_rem = 0, n_steps = 0;
   const int frame = blockIdx.x;
@@ -92,11 +114,20 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
   int* cursor = hist + nb;           // nb: fill cursor, then END of bin b's (compacted) cell list
   float* stage = reinterpret_cast<float*>(cursor + nb);  // kRW waves x 32 entries x 9 floats (2304 floats for 8 waves)
   float* mse_l = stage + kStageFloats;                     // FULL: C floats
-  uint16_t* qpos = reinterpret_cast<uint16_t*>(mse_l + (FULL ? C : 0));
-  uint16_t* queue = qpos + C;
-  uint16_t* order = queue + C;
-  uint16_t* binof = order + C;  // FULL: C (bin + 1)
-  uint16_t* bin_start = binof + (FULL ? C : 0);  // nb + 1 (+1 pad): begin of bin b's cell list
+  unsigned char* lp = reinterpret_cast<unsigned char*>(mse_l + (FULL ? C : 0));
+  idx_t *qpos, *queue, *order;
+  if constexpr (GST) {
+    qpos = rx.g_qpos + static_cast<size_t>(frame) * C;
+    queue = rb.g_queue + static_cast<size_t>(frame) * C;
+    order = rb.order + static_cast<size_t>(frame) * C;
+  } else {
+    qpos = reinterpret_cast<idx_t*>(lp);
+    queue = qpos + C;
+    order = queue + C;
+    lp = reinterpret_cast<unsigned char*>(order + C);
+  }
+  uint16_t* binof = reinterpret_cast<uint16_t*>(lp);  // FULL: C (bin + 1)
+  idx_t* bin_start = reinterpret_cast<idx_t*>(binof + (FULL ? C : 0));  // nb + 1 (+1 pad): begin of bin b's cell list
   uint8_t* flags = reinterpret_cast<uint8_t*>(bin_start + nb + 2);
   // (the list of non-empty bins lives in the first nb uint16 of `stage` during P1; stage is not used before P2)
   uint16_t* nzlist = reinterpret_cast<uint16_t*>(stage);
@@ -165,11 +196,25 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
         bin1 = m >> META_BIN_SHIFT;
       }
       flags[c] = static_cast<uint8_t>(fl);
-      qpos[c] = 0xFFFFu;
+      qpos[c] = static_cast<idx_t>(kNoPos);
       if (fl & F_UNASSIGNED) {
         ++planar_cnt;
         const int b = static_cast<int>(bin1) - 1;
-        if (b >= 0 && b < nb) atomicAdd(&hist[b], 1);
+        if (FULL && b >= 0 && b < nb) atomicAdd(&hist[b], 1);
+      }
+    }
+    if constexpr (!FULL) {  // bin counts and list bounds come from the sorted seed lists
+      const uint32_t* bo = rx.bin_off + static_cast<size_t>(frame) * (nb + 1);
+      for (int b = tid; b < nb; b += kRT) {
+        const uint32_t s0 = bo[b], s1 = bo[b + 1];
+        hist[b] = static_cast<int>(s1 - s0);
+        bin_start[b] = static_cast<idx_t>(s0);
+        cursor[b] = static_cast<int>(s1);
+      }
+      if constexpr (!GST) {
+        const uint32_t* go = rb.order + static_cast<size_t>(frame) * C;
+        const int listed = static_cast<int>(bo[nb]);
+        for (int i = tid; i < listed; i += kRT) order[i] = static_cast<idx_t>(go[i]);
       }
     }
     planar_cnt = wave_sum(planar_cnt);
@@ -182,8 +227,8 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
       const int b = base + lane;
       const int v = b < nb ? hist[b] : 0;
       const int incl = wave_incl_scan(v, lane);
-      if (b < nb) {
-        bin_start[b] = static_cast<uint16_t>(carry + incl - v);
+      if (FULL && b < nb) {
+        bin_start[b] = static_cast<idx_t>(carry + incl - v);
         cursor[b] = carry + incl - v;
       }
       carry += __shfl(incl, 63);
@@ -193,17 +238,19 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
       if (lane == 0) hdr[5] += __popcll(nzm);
       wave_sync();
     }
-    if (lane == 0) bin_start[nb] = static_cast<uint16_t>(carry);
+    if (lane == 0) bin_start[nb] = static_cast<idx_t>(carry);
   }
   __syncthreads();
-  for (int c = tid; c < C; c += kRT) {
-    const uint32_t f = flags[c];
-    if (f & F_UNASSIGNED) {
-      const int b = (FULL ? static_cast<int>(binof[c]) : static_cast<int>(meta[c] >> META_BIN_SHIFT)) - 1;
-      if (b >= 0 && b < nb) order[atomicAdd(&cursor[b], 1)] = static_cast<uint16_t>(c);
+  if constexpr (FULL) {
+    for (int c = tid; c < C; c += kRT) {
+      const uint32_t f = flags[c];
+      if (f & F_UNASSIGNED) {
+        const int b = static_cast<int>(binof[c]) - 1;
+        if (b >= 0 && b < nb) order[atomicAdd(&cursor[b], 1)] = static_cast<uint16_t>(c);
+      }
     }
+    __syncthreads();
   }
-  __syncthreads();
   }  // PHASE <= 1
   if (PHASE == 1) {
     for (int i = tid; i < img_vec; i += static_cast<int>(blockDim.x)) img[i] = lds_v[i];
@@ -227,62 +274,90 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
     const uint32_t notme = ~(1u << opp) & 0xFu;
     for (int guard = 0; remaining > 0 && guard <= C; ++guard) {
       const unsigned long long ta = DPX_STAMP();
-      // most frequent bin, lowest index among maxima: key = count << 16 | (0xFFFF - bin)
+      // most frequent bin, lowest index among maxima: key = count << kBinBits | (kBinMask - bin)
+      constexpr int kBinBits = GST ? 13 : 16;  // tier 0: counts up to 2^19, bins < 2^13
+      constexpr uint32_t kBinMask = (1u << kBinBits) - 1u;
       uint32_t key = 0;
       if (reg_bins) {
-        if (mybin >= 0) key = (static_cast<uint32_t>(hist[mybin]) << 16) | static_cast<uint32_t>(0xFFFF - mybin);
+        if (mybin >= 0) key = (static_cast<uint32_t>(hist[mybin]) << kBinBits) | (kBinMask - static_cast<uint32_t>(mybin));
       } else {
         for (int t = lane; t < nnz; t += 64) {
           const int b = nzlist[t];
-          const uint32_t k = (static_cast<uint32_t>(hist[b]) << 16) | static_cast<uint32_t>(0xFFFF - b);
+          const uint32_t k = (static_cast<uint32_t>(hist[b]) << kBinBits) | (kBinMask - static_cast<uint32_t>(b));
           key = k > key ? k : key;
         }
       }
       key = wave_max_u32(key);
-      const int bv = static_cast<int>(key >> 16);
-      const int bb = 0xFFFF - static_cast<int>(key & 0xFFFFu);
+      const int bv = static_cast<int>(key >> kBinBits);
+      const int bb = static_cast<int>(kBinMask - (key & kBinMask));
       if (bv <= 0) break;
       if (static_cast<unsigned long long>(bv) < static_cast<unsigned long long>(static_cast<long long>(prm.min_cand))) break;
       const unsigned long long tb = DPX_STAMP();
-      // min-MSE candidate, lowest cell id among equals; the scan compacts the bin's list (drops grown cells) in place
-      const int s = bin_start[bb], e = cursor[bb];
-      uint32_t bm = 0xFFFFFFFFu, bi = 0xFFFFFFFFu, anyc = 0xFFFFFFFFu;
-      int outp = s;
-      for (int base = s; base < e; base += 64) {
-        const int i = base + lane;
-        uint32_t c = 0;
-        bool alive = false;
-        if (i < e) {
-          c = order[i];
-          alive = (flags[c] & F_UNASSIGNED) != 0;
-        }
-        const unsigned long long am = __ballot(alive);
-        if (alive) {
-          order[outp + __popcll(am & lt_mask)] = static_cast<uint16_t>(c);
-          anyc = c < anyc ? c : anyc;
-          float m = FULL ? mse_l[c] : mse_c[c];
-          if (static_cast<double>(m) < 2147483647.0) {
-            m = m + 0.0f;  // -0 -> +0: the reference's float compare treats them as equal
-            const uint32_t om = ordered_f32(m);
-            if (om < bm || (om == bm && c < bi)) {
-              bm = om;
-              bi = c;
+      uint32_t seed = 0xFFFFFFFFu;
+      if constexpr (FULL) {
+        // min-MSE candidate, lowest cell id among equals; the scan compacts the bin's list (drops grown cells) in place
+        const int s = bin_start[bb], e = cursor[bb];
+        uint32_t bm = 0xFFFFFFFFu, bi = 0xFFFFFFFFu, anyc = 0xFFFFFFFFu;
+        int outp = s;
+        for (int base = s; base < e; base += 64) {
+          const int i = base + lane;
+          uint32_t c = 0;
+          bool alive = false;
+          if (i < e) {
+            c = order[i];
+            alive = (flags[c] & F_UNASSIGNED) != 0;
+          }
+          const unsigned long long am = __ballot(alive);
+          if (alive) {
+            order[outp + __popcll(am & lt_mask)] = static_cast<uint16_t>(c);
+            anyc = c < anyc ? c : anyc;
+            float m = FULL ? mse_l[c] : mse_c[c];
+            if (static_cast<double>(m) < 2147483647.0) {
+              m = m + 0.0f;  // -0 -> +0: the reference's float compare treats them as equal
+              const uint32_t om = ordered_f32(m);
+              if (om < bm || (om == bm && c < bi)) {
+                bm = om;
+                bi = c;
+              }
             }
           }
+          outp += __popcll(am);
         }
-        outp += __popcll(am);
+        if (lane == 0) cursor[bb] = outp;
+        const uint32_t gm = wave_min_u32(bm);
+        bi = wave_min_u32(bm == gm ? bi : 0xFFFFFFFFu);
+        seed = (gm != 0xFFFFFFFFu) ? bi : wave_min_u32(anyc);
+      } else {
+        // the bin's list is sorted by (mse, cell id): the seed is its first live entry.  bin_start[bb] only moves
+        // forward (a grown cell never comes back), so every list entry is skipped at most once per frame.
+        int s0 = static_cast<int>(bin_start[bb]);
+        const int e = cursor[bb];
+        while (s0 < e) {
+          const int i = s0 + lane;
+          uint32_t c = 0;
+          bool alive = false;
+          if (i < e) {
+            c = order[i];
+            alive = (flags[c] & F_UNASSIGNED) != 0;
+          }
+          const unsigned long long am = __ballot(alive);
+          if (am) {
+            const int first = __builtin_ctzll(am);
+            seed = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c), first));
+            s0 += first + 1;
+            break;
+          }
+          s0 += 64;
+        }
+        if (lane == 0) bin_start[bb] = static_cast<idx_t>(s0 < e ? s0 : e);
       }
-      if (lane == 0) cursor[bb] = outp;
-      const uint32_t gm = wave_min_u32(bm);
-      bi = wave_min_u32(bm == gm ? bi : 0xFFFFFFFFu);
-      const uint32_t seed = (gm != 0xFFFFFFFFu) ? bi : wave_min_u32(anyc);
       if (seed == 0xFFFFFFFFu) break;
 
       const unsigned long long tc = DPX_STAMP();
       const int gstart = tail;
       if (lane == 0) {
-        queue[tail] = static_cast<uint16_t>(seed);
-        qpos[seed] = static_cast<uint16_t>(tail);
+        queue[tail] = static_cast<idx_t>(seed);
+        qpos[seed] = static_cast<idx_t>(tail);
         flags[seed] = static_cast<uint8_t>(flags[seed] & ~F_UNASSIGNED);
         atomicSub(&hist[bb], 1);  // hist.removePoint(seed); the seed's bin is bb
       }
@@ -317,8 +392,8 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
         const unsigned long long mask = __ballot(win);
         if (win) {
           const int pos = tail + __popcll(mask & lt_mask);
-          queue[pos] = static_cast<uint16_t>(v);
-          qpos[v] = static_cast<uint16_t>(pos);
+          queue[pos] = static_cast<idx_t>(v);
+          qpos[v] = static_cast<idx_t>(pos);
           flags[v] = static_cast<uint8_t>(fv & ~F_UNASSIGNED);
           const int b = (FULL ? static_cast<int>(binof[v]) : static_cast<int>(meta[v] >> META_BIN_SHIFT)) - 1;
           if (b >= 0 && b < nb) atomicSub(&hist[b], 1);  // hist.removePoint at activation time
@@ -360,7 +435,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
   t_p1 = DPX_STAMP();
 
   // `order` is dead after the seed loop: it becomes the uint16 label map of P4/P5 (labels_map_)
-  uint16_t* lab16 = order;
+  idx_t* lab16 = order;
   for (int c = tid; c < C; c += kRT) lab16[c] = 0;
   // ---------------- P2: exact float accumulation of every candidate segment (wave per segment) ------------
   {
@@ -454,122 +529,75 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
     if (id1 == 0) continue;
     const int gi = __float_as_int(co[10]);
     const int gs = static_cast<int>(grow_start[gi]), ge = static_cast<int>(grow_start[gi + 1]);
-    for (int i = gs + lane; i < ge; i += 64) lab16[queue[i]] = static_cast<uint16_t>(id1);
+    for (int i = gs + lane; i < ge; i += 64) lab16[queue[i]] = static_cast<idx_t>(id1);
   }
   __syncthreads();
   t_p4 = DPX_STAMP();
 
-  // ---------------- P5: findMergedLabels, wave 0 ------------------------------------------------------------
-  // Fast path (plane count up to a few hundred): the symmetric adjacency bit matrix, a 7-float view of every plane
-  // (normal, d, mean) and the merge labels live in LDS.  Otherwise: adjacency pair list in global memory, one bit
-  // row rebuilt per plane (as in dpx_regions.h).
+  // ---------------- P5: findMergedLabels ---------------------------------------------------------------------
+  // getConnectedComponents (plane_extractor.cpp:430-453) looks at rows 0..nv-2 x cols 0..nh-2 of labels_map_, right and
+  // down neighbour, symmetrised; findMergedLabels (:394-428) then walks the planes in id order and tests, against the
+  // current parameters of merge[row], every adjacent plane with a larger id, folding accepted ones in ascending order.
+  // Small plane counts (up to a few hundred): adjacency bit matrix, a 7-float view of every plane and the merge labels
+  // in LDS, wave 0 only.  Larger counts: the workgroup builds a CSR adjacency (lower id -> higher ids) in global
+  // scratch with a counting sort, then wave 0 walks only the non-empty rows.
   int merges = 0;
-  if (nplanes > 0 && wid == 0) {
-    const int wpr = (nplanes + 31) >> 5;  // words per matrix row
-    constexpr int kMatWords = 2304;       // stage holds at least 2304 words
+  const int wpr = (nplanes + 31) >> 5;  // words per adjacency bit row
+  constexpr int kMatWords = 2304;       // stage holds at least 2304 words
+  const bool fast = nplanes * 32 <= 4 * C && nplanes * wpr <= kMatWords;
+  const int gw = nh - 1, gh = nv - 1;
+  const int gtotal = gw > 0 && gh > 0 ? gw * gh : 0;
+  // merge test of the row plane (pnx.., pd) against a column plane (plane_extractor.cpp:405-412)
+  auto merge_test = [&](float pnx, float pny, float pnz, float pd, float cnx, float cny, float cnz, float cmx, float cmy, float cmz) {
+    const float cosv = dot3(pnx, pny, pnz, cnx, cny, cnz);
+    const float tf = dot3(pnx, pny, pnz, cmx, cmy, cmz) + pd;  // float add (plane_extractor.cpp:410-411)
+    const double dist = static_cast<double>(tf) * static_cast<double>(tf);
+    return static_cast<double>(cosv) > static_cast<double>(prm.min_cos) && dist < static_cast<double>(prm.max_merge_dist);
+  };
+  if (nplanes > 0 && fast && wid == 0) {
     uint32_t* mat = reinterpret_cast<uint32_t*>(stage);
     float* pview = reinterpret_cast<float*>(qpos);                   // qpos|queue are dead: 4*C bytes
     int32_t* lmerge = reinterpret_cast<int32_t*>(pview + 7 * nplanes);
-    const bool fast = nplanes * 32 <= 4 * C && nplanes * wpr <= kMatWords;
-    const int gw = nh - 1, gh = nv - 1;
-    const int total = gw > 0 && gh > 0 ? gw * gh : 0;
-    int npairs = 0;
-    if (fast) {
-      for (int w = lane; w < nplanes * wpr; w += 64) mat[w] = 0;
-      for (int i = lane; i < nplanes; i += 64) {
-        const dpx_plane& pl = planes[i];
-        float* pv = pview + i * 7;
-        pv[0] = pl.normal[0]; pv[1] = pl.normal[1]; pv[2] = pl.normal[2]; pv[3] = pl.d;
-        pv[4] = pl.mean[0]; pv[5] = pl.mean[1]; pv[6] = pl.mean[2];
-        lmerge[i] = i;
-      }
-      wave_sync();
-      // getConnectedComponents (plane_extractor.cpp:430-453): rows 0..nv-2 x cols 0..nh-2, right and down neighbour,
-      // symmetrised
-      for (int base = 0; base < total; base += 64) {
-        const int idx = base + lane;
-        if (idx < total) {
-          const int r = idx / gw, c = idx - r * gw;
-          const int a = lab16[r * nh + c];
-          const int right = lab16[r * nh + c + 1];
-          const int down = lab16[(r + 1) * nh + c];
-          if (a > 0 && right > 0 && a != right) {
-            atomicOr(&mat[(a - 1) * wpr + ((right - 1) >> 5)], 1u << ((right - 1) & 31));
-            atomicOr(&mat[(right - 1) * wpr + ((a - 1) >> 5)], 1u << ((a - 1) & 31));
-          }
-          if (a > 0 && down > 0 && a != down) {
-            atomicOr(&mat[(a - 1) * wpr + ((down - 1) >> 5)], 1u << ((down - 1) & 31));
-            atomicOr(&mat[(down - 1) * wpr + ((a - 1) >> 5)], 1u << ((a - 1) & 31));
-          }
+    for (int w = lane; w < nplanes * wpr; w += 64) mat[w] = 0;
+    for (int i = lane; i < nplanes; i += 64) {
+      const dpx_plane& pl = planes[i];
+      float* pv = pview + i * 7;
+      pv[0] = pl.normal[0]; pv[1] = pl.normal[1]; pv[2] = pl.normal[2]; pv[3] = pl.d;
+      pv[4] = pl.mean[0]; pv[5] = pl.mean[1]; pv[6] = pl.mean[2];
+      lmerge[i] = i;
+    }
+    wave_sync();
+    for (int base = 0; base < gtotal; base += 64) {
+      const int idx = base + lane;
+      if (idx < gtotal) {
+        const int r = idx / gw, c = idx - r * gw;
+        const int a = lab16[r * nh + c];
+        const int right = lab16[r * nh + c + 1];
+        const int down = lab16[(r + 1) * nh + c];
+        if (a > 0 && right > 0 && a != right) {
+          atomicOr(&mat[(a - 1) * wpr + ((right - 1) >> 5)], 1u << ((right - 1) & 31));
+          atomicOr(&mat[(right - 1) * wpr + ((a - 1) >> 5)], 1u << ((a - 1) & 31));
         }
-      }
-    } else {
-      for (int base = 0; base < total; base += 64) {
-        const int idx = base + lane;
-        bool hp = false, vp = false;
-        int a = 0, right = 0, down = 0;
-        if (idx < total) {
-          const int r = idx / gw, c = idx - r * gw;
-          a = lab16[r * nh + c];
-          right = lab16[r * nh + c + 1];
-          down = lab16[(r + 1) * nh + c];
-          hp = a > 0 && right > 0 && a != right;
-          vp = a > 0 && down > 0 && a != down;
-          if (hp && r > 0 && lab16[(r - 1) * nh + c] == a && lab16[(r - 1) * nh + c + 1] == right) hp = false;
-          if (vp && c > 0 && lab16[r * nh + c - 1] == a && lab16[(r + 1) * nh + c - 1] == down) vp = false;
+        if (a > 0 && down > 0 && a != down) {
+          atomicOr(&mat[(a - 1) * wpr + ((down - 1) >> 5)], 1u << ((down - 1) & 31));
+          atomicOr(&mat[(down - 1) * wpr + ((a - 1) >> 5)], 1u << ((a - 1) & 31));
         }
-        unsigned long long m1 = __ballot(hp);
-        if (hp) pairs[npairs + __popcll(m1 & lt_mask)] = make_uint2(static_cast<uint32_t>(a - 1), static_cast<uint32_t>(right - 1));
-        npairs += __popcll(m1);
-        m1 = __ballot(vp);
-        if (vp) pairs[npairs + __popcll(m1 & lt_mask)] = make_uint2(static_cast<uint32_t>(a - 1), static_cast<uint32_t>(down - 1));
-        npairs += __popcll(m1);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     wave_sync();
-    uint32_t* slowbits = reinterpret_cast<uint32_t*>(qpos);  // slow path bit row: 4*C bytes >= nplanes bits
     for (int row = 0; row < nplanes; ++row) {
-      const uint32_t* rowbits;
-      if (fast) {
-        rowbits = mat + row * wpr;
-      } else {
-        for (int w = lane; w < wpr; w += 64) slowbits[w] = 0;
-        wave_sync();
-        for (int i = lane; i < npairs; i += 64) {
-          const uint2 p = pairs[i];
-          if (static_cast<int>(p.x) == row) atomicOr(&slowbits[p.y >> 5], 1u << (p.y & 31));
-          if (static_cast<int>(p.y) == row) atomicOr(&slowbits[p.x >> 5], 1u << (p.x & 31));
-        }
-        wave_sync();
-        rowbits = slowbits;
-      }
-      const int pid = fast ? lmerge[row] : merge[row];
-      float pnx, pny, pnz, pd;
-      if (fast) {
-        const float* pv = pview + pid * 7;
-        pnx = pv[0]; pny = pv[1]; pnz = pv[2]; pd = pv[3];
-      } else {
-        const dpx_plane& pp_ = planes[pid];
-        pnx = pp_.normal[0]; pny = pp_.normal[1]; pnz = pp_.normal[2]; pd = pp_.d;
-      }
+      const uint32_t* rowbits = mat + row * wpr;
+      const int pid = lmerge[row];
+      const float* pv = pview + pid * 7;
+      const float pnx = pv[0], pny = pv[1], pnz = pv[2], pd = pv[3];
       bool expanded = false;
       for (int cbase = row + 1; cbase < nplanes; cbase += 64) {
         const int col = cbase + lane;
         bool acc = false;
         if (col < nplanes && ((rowbits[col >> 5] >> (col & 31)) & 1u)) {
-          float cnx, cny, cnz, cmx, cmy, cmz;
-          if (fast) {
-            const float* cv = pview + col * 7;
-            cnx = cv[0]; cny = cv[1]; cnz = cv[2]; cmx = cv[4]; cmy = cv[5]; cmz = cv[6];
-          } else {
-            const dpx_plane& pc = planes[col];
-            cnx = pc.normal[0]; cny = pc.normal[1]; cnz = pc.normal[2]; cmx = pc.mean[0]; cmy = pc.mean[1]; cmz = pc.mean[2];
-          }
-          const float cosv = dot3(pnx, pny, pnz, cnx, cny, cnz);
-          const float tf = dot3(pnx, pny, pnz, cmx, cmy, cmz) + pd;  // float add (plane_extractor.cpp:410-411)
-          const double dist = static_cast<double>(tf) * static_cast<double>(tf);
-          acc = static_cast<double>(cosv) > static_cast<double>(prm.min_cos) && dist < static_cast<double>(prm.max_merge_dist);
+          const float* cv = pview + col * 7;
+          acc = merge_test(pnx, pny, pnz, pd, cv[0], cv[1], cv[2], cv[4], cv[5], cv[6]);
         }
         unsigned long long mask = __ballot(acc);
         while (mask) {
@@ -582,7 +610,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
           if (lane == 9) planes[pid].n_pts += planes[colx].n_pts;
           if (lane == 10) {
             merge[colx] = pid;
-            if (fast) lmerge[colx] = pid;
+            lmerge[colx] = pid;
           }
           expanded = true;
           ++merges;
@@ -598,17 +626,153 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
           pl.mean[0] = fit.mean[0]; pl.mean[1] = fit.mean[1]; pl.mean[2] = fit.mean[2];
           pl.normal[0] = fit.normal[0]; pl.normal[1] = fit.normal[1]; pl.normal[2] = fit.normal[2];
           pl.d = fit.d; pl.mse = fit.mse; pl.score = fit.score;
-          if (fast) {
-            float* pv = pview + pid * 7;
-            pv[0] = fit.normal[0]; pv[1] = fit.normal[1]; pv[2] = fit.normal[2]; pv[3] = fit.d;
-            pv[4] = fit.mean[0]; pv[5] = fit.mean[1]; pv[6] = fit.mean[2];
-          }
+          float* pw = pview + pid * 7;
+          pw[0] = fit.normal[0]; pw[1] = fit.normal[1]; pw[2] = fit.normal[2]; pw[3] = fit.d;
+          pw[4] = fit.mean[0]; pw[5] = fit.mean[1]; pw[6] = fit.mean[2];
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       }
       wave_sync();
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  }
+  if (nplanes > 0 && !fast) {
+    // ---- CSR adjacency in the pair scratch (4*C words): cnt[C] | off[C + 2] | cols[<= 2*gtotal]
+    uint32_t* adj = reinterpret_cast<uint32_t*>(pairs);
+    uint32_t* cnt = adj;
+    uint32_t* off = adj + C;
+    uint32_t* cols = adj + 2 * static_cast<size_t>(C) + 2;
+    uint32_t* part = reinterpret_cast<uint32_t*>(stage);  // kRT partial sums
+    for (int i = tid; i < nplanes; i += kRT) cnt[i] = 0;
+    __syncthreads();
+    // a label pair that the grid row above (horizontal pairs) / the grid column to the left (vertical pairs) already
+    // produced is skipped; the remaining duplicates are harmless (the row walk takes each column once)
+    auto grid_pairs = [&](int idx, int& h_lo, int& h_hi, int& v_lo, int& v_hi) {
+      const int r = idx / gw, c = idx - r * gw;
+      const int a = lab16[r * nh + c];
+      const int right = lab16[r * nh + c + 1];
+      const int down = lab16[(r + 1) * nh + c];
+      bool hp = a > 0 && right > 0 && a != right;
+      bool vp = a > 0 && down > 0 && a != down;
+      if (hp && r > 0 && static_cast<int>(lab16[(r - 1) * nh + c]) == a && static_cast<int>(lab16[(r - 1) * nh + c + 1]) == right) hp = false;
+      if (vp && c > 0 && static_cast<int>(lab16[r * nh + c - 1]) == a && static_cast<int>(lab16[(r + 1) * nh + c - 1]) == down) vp = false;
+      h_lo = hp ? (a < right ? a : right) - 1 : -1;
+      h_hi = (a < right ? right : a) - 1;
+      v_lo = vp ? (a < down ? a : down) - 1 : -1;
+      v_hi = (a < down ? down : a) - 1;
+    };
+    for (int idx = tid; idx < gtotal; idx += kRT) {
+      int hl, hh, vl, vh;
+      grid_pairs(idx, hl, hh, vl, vh);
+      if (hl >= 0) atomicAdd(&cnt[hl], 1u);
+      if (vl >= 0) atomicAdd(&cnt[vl], 1u);
+    }
+    __syncthreads();
+    {  // exclusive scan of cnt -> off; cnt becomes the fill cursor
+      const int per = (nplanes + kRT - 1) / kRT;
+      const int i0 = tid * per, i1 = (i0 + per) < nplanes ? (i0 + per) : nplanes;
+      uint32_t sum = 0;
+      for (int i = i0; i < i1; ++i) sum += cnt[i];
+      part[tid] = sum;
+      __syncthreads();
+      uint32_t base = 0;
+      for (int t = 0; t < tid; ++t) base += part[t];
+      for (int i = i0; i < i1; ++i) {
+        const uint32_t v = cnt[i];
+        off[i] = base;
+        cnt[i] = 0;
+        base += v;
+      }
+      if (tid == kRT - 1) off[nplanes] = base;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < gtotal; idx += kRT) {
+      int hl, hh, vl, vh;
+      grid_pairs(idx, hl, hh, vl, vh);
+      if (hl >= 0) cols[off[hl] + atomicAdd(&cnt[hl], 1u)] = static_cast<uint32_t>(hh);
+      if (vl >= 0) cols[off[vl] + atomicAdd(&cnt[vl], 1u)] = static_cast<uint32_t>(vh);
+    }
+    __syncthreads();
+    if (wid == 0) {
+      uint32_t* slowbits = reinterpret_cast<uint32_t*>(qpos);  // bit row for planes with more than 64 adjacency entries
+      for (int rbase = 0; rbase < nplanes; rbase += 64) {
+        const int rr = rbase + lane;
+        const uint32_t o0 = rr < nplanes ? off[rr] : 0u, o1 = rr < nplanes ? off[rr + 1] : 0u;
+        unsigned long long todo = __ballot(o1 > o0);
+        while (todo) {
+          const int rl = __builtin_ctzll(todo);
+          todo &= todo - 1;
+          const int row = rbase + rl;
+          const int s0 = __builtin_amdgcn_readlane(static_cast<int>(o0), rl), e0 = __builtin_amdgcn_readlane(static_cast<int>(o1), rl);
+          const int deg = e0 - s0;
+          const int pid = merge[row];
+          const dpx_plane& pp_ = planes[pid];
+          const float pnx = pp_.normal[0], pny = pp_.normal[1], pnz = pp_.normal[2], pd = pp_.d;
+          bool expanded = false;
+          auto fold = [&](int colx) {  // plane_extractor.cpp:413-417: accumulate the column's sums into the row's plane
+            float* pf = reinterpret_cast<float*>(&planes[pid]);
+            const float* cfp = reinterpret_cast<const float*>(&planes[colx]);
+            if (lane < 9) pf[lane] = pf[lane] + cfp[lane];
+            if (lane == 9) planes[pid].n_pts += planes[colx].n_pts;
+            if (lane == 10) merge[colx] = pid;
+            expanded = true;
+            ++merges;
+          };
+          if (deg <= rx.csr_chunk) {
+            const uint32_t col = lane < deg ? cols[s0 + lane] : 0xFFFFFFFFu;
+            bool acc = false;
+            if (lane < deg) {
+              const dpx_plane& pc = planes[col];
+              acc = merge_test(pnx, pny, pnz, pd, pc.normal[0], pc.normal[1], pc.normal[2], pc.mean[0], pc.mean[1], pc.mean[2]);
+            }
+            // accepted columns in ascending order; duplicates of a column are retired together
+            while (__ballot(acc)) {
+              const uint32_t cmin = wave_min_u32(acc ? col : 0xFFFFFFFFu);
+              if (col == cmin) acc = false;
+              fold(static_cast<int>(cmin));
+            }
+          } else {
+            for (int w = lane; w < wpr; w += 64) slowbits[w] = 0;
+            wave_sync();
+            for (int i = s0 + lane; i < e0; i += 64) {
+              const uint32_t c = cols[i];
+              atomicOr(&slowbits[c >> 5], 1u << (c & 31));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            wave_sync();
+            for (int cbase = row + 1; cbase < nplanes; cbase += 64) {
+              const int col = cbase + lane;
+              bool acc = false;
+              if (col < nplanes && ((slowbits[col >> 5] >> (col & 31)) & 1u)) {
+                const dpx_plane& pc = planes[col];
+                acc = merge_test(pnx, pny, pnz, pd, pc.normal[0], pc.normal[1], pc.normal[2], pc.mean[0], pc.mean[1], pc.mean[2]);
+              }
+              unsigned long long mask = __ballot(acc);
+              while (mask) {
+                const int l = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                fold(cbase + l);
+              }
+            }
+          }
+          if (expanded) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            wave_sync();
+            if (lane == 0) {
+              dpx_plane& pl = planes[pid];
+              PlaneFit fit;
+              fit_plane(pl.sum, pl.pp, pl.n_pts, fit);
+              pl.mean[0] = fit.mean[0]; pl.mean[1] = fit.mean[1]; pl.mean[2] = fit.mean[2];
+              pl.normal[0] = fit.normal[0]; pl.normal[1] = fit.normal[1]; pl.normal[2] = fit.normal[2];
+              pl.d = fit.d; pl.mse = fit.mse; pl.score = fit.score;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          wave_sync();
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
   }
   __syncthreads();
   t_p5 = DPX_STAMP();
@@ -617,7 +781,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
     const int L = lab16[c];
     const int fin = (L == 0 || nplanes == 0) ? 0 : merge[L - 1] + 1;
     cell_labels[c] = fin;
-    lab16[c] = static_cast<uint16_t>(fin);  // final labels stay in LDS for the fused expansion below
+    lab16[c] = static_cast<idx_t>(fin);  // final labels stay in LDS for the fused expansion below
   }
   if (nplanes > 0)
     for (int i = tid; i < nplanes; i += kRT) planes[i].merge_label = merge[i];

@@ -204,10 +204,11 @@ def test_ragged_and_tiny_images(D, oracle):
         full_compare(D, oracle, depth, synth.intrinsics_for(h, w), oracle.default_config())
 
 
-@pytest.mark.parametrize("env", ["DPX_FORCE_GLOBAL_STATE", "DPX_REGIONS_V1", "DPX_REGIONS_LEAN", "DPX_NO_FASTDIV", "DPX_PLANEFIT_V1", "DPX_LABELS_V1", "DPX_REGIONS_NOSPLIT", "DPX_NO_FUSED_LABELS"])
+@pytest.mark.parametrize("env", ["DPX_FORCE_GLOBAL_STATE", "DPX_REGIONS_V1", "DPX_REGIONS_LEAN", "DPX_REGIONS_GSTATE", "DPX_NO_FASTDIV", "DPX_PLANEFIT_V1", "DPX_LABELS_V1", "DPX_REGIONS_NOSPLIT", "DPX_NO_FUSED_LABELS"])
 def test_kernel_variants(D, oracle, env):
     """Every kernel variant must give the same bits: region growing with its per-cell state in global memory
-    (used when a frame does not fit LDS), the v1 single-wave kernel, the lean LDS tier (mse/bin read from global),
+    (used when a frame does not fit LDS), the v1 single-wave kernel, the lean LDS tier and the flag-byte-only tier (both
+    seeded from bin lists sorted by a bitonic network; the latter keeps queues in global memory with 32-bit indices),
     the plane-fit kernel with IEEE division instead of the verified reciprocal sequence, and the generic v1
     plane-fit kernel."""
     os.environ[env] = "1"
@@ -222,6 +223,23 @@ def test_kernel_variants(D, oracle, env):
                      oracle.config_from_ini(synth.ICL_INI))
     finally:
         del os.environ[env]
+
+
+@pytest.mark.parametrize("env", [None, "DPX_CSR_CHUNK"])
+def test_large_frames(D, oracle, env):
+    """BASELINE configs 3 and 5 in small: 1280x960 (lean LDS tier, hundreds of planes -> CSR merge walk) and one
+    3840x2160 frame (82 944 cells: flag byte in LDS, queues in global memory, 32-bit indices, thousands of grows)."""
+    if env:
+        os.environ[env] = "1"  # every adjacency row takes the wide (bit-row) walk
+    try:
+        depth = np.stack([synth.synth_depth(960, 1280, seed=s) for s in (0, 6)])
+        full_compare(D, oracle, depth, synth.intrinsics_for(960, 1280), oracle.default_config())
+        if env is None:
+            depth = synth.synth_depth(2160, 3840, seed=0)[None]
+            full_compare(D, oracle, depth, synth.intrinsics_for(2160, 3840), oracle.default_config())
+    finally:
+        if env:
+            del os.environ[env]
 
 
 def test_fast_division_is_verified(D):

@@ -1,4 +1,5 @@
-"""Diagnostic: per-phase shader-clock cycles of the region-growing kernel on the bench workload (one frame)."""
+"""Diagnostic: per-phase shader-clock cycles of the region-growing kernel (s_memtime, 100 MHz on gfx950).
+usage: region_phases.py [H W batch]   (default: the bench workload, 64 TUM-like 640x480 frames)"""
 import sys
 from pathlib import Path
 import numpy as np
@@ -8,16 +9,22 @@ import deplex_amd as D
 from deplex_amd import _capi
 import synth
 
-depth = synth.tum_stream(64)
-K = synth.read_K(synth.TUM_K)
-intr = tuple(float(v) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2]))
-ex = D.PlaneExtractor(480, 640, max_batch=64)
+if len(sys.argv) >= 4:
+    h, w, B = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    depth = synth.synth_batch(B, h, w, seed0=0)
+    intr = synth.intrinsics_for(h, w)
+else:
+    h, w, B = 480, 640, 64
+    depth = synth.tum_stream(64)
+    K = synth.read_K(synth.TUM_K)
+    intr = tuple(float(v) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2]))
+ex = D.PlaneExtractor(h, w, max_batch=B)
 _capi.check(_capi.lib().dpx_debug_region_phases(ex._h, 1, 0, None))
 for rep in range(2):
     ex.process_depth_batch(depth, *intr)
 names = ["P0 load", "P1 seeds+bfs", "P2 accum", "P3 fits", "P4 labels", "P5 merge", "P6 final", "total",
          "sum argmax", "sum seed", "sum bfs", "sum removal", "bfs steps", "grows", "cands", "activations"]
-for f in (0, 1, 17):
+for f in sorted(set((0, 1, B - 1))):
     out = np.zeros(16, dtype=np.uint64)
     _capi.check(_capi.lib().dpx_debug_region_phases(ex._h, 1, f, out.ctypes.data))
-    print(f"frame {f}: " + ", ".join(f"{n}={int(v)}" for n, v in zip(names, out)))
+    print(f"frame {f}: " + ", ".join(f"{n}={int(v)}" for n, v in zip(names, out)), "stats", ex.frame_stats(f))

@@ -1,10 +1,11 @@
 """Summarise a rocprofv3 kernel trace CSV: per-kernel durations and average concurrency in the steady-state window."""
-import csv, sys, random
+import csv, re, sys, random
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = []
 for r in rows:
     n = r['Kernel_Name']
-    k = 'pf' if 'planefit' in n else ('reg' + (n[n.find('Li') + 2] if 'regions2' in n and 'ELi' in n else '')) if 'regions' in n else 'lab' if 'labels' in n else None
+    m = re.search(r'k_regions2<\w+, \w+, (\d)>', n) or re.search(r'k_regions2ILb\dELb\dELi(\d)E', n)
+    k = 'pf' if 'planefit' in n else ('reg' + (m.group(1) if m else '')) if 'regions' in n else 'lab' if 'labels' in n else None
     if k: ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), k))
 ev.sort()
 s = ev[len(ev) // 4][0]; e = ev[3 * len(ev) // 4][1]
@@ -16,3 +17,5 @@ for k in kinds:
     d = [(b - a) / 1e3 for a, b, kk in ev if kk == k and a >= s and b <= e]
     c = [sum(1 for a, b, kk in ev if kk == k and a <= t < b) for t in ts]
     if d: print(f"  {k}: n={len(d)} avg {sum(d)/len(d):.1f} us (min {min(d):.1f}, max {max(d):.1f}); avg concurrent {sum(c)/len(c):.2f}")
+tot = [sum(1 for a, b, kk in ev if a <= t < b) for t in ts]
+print(f"  all kernels: avg concurrent {sum(tot)/len(tot):.2f}, max {max(tot)}, idle fraction {sum(1 for c in tot if c == 0)/len(tot):.2f}")
