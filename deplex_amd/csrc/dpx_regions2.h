@@ -265,8 +265,12 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
     int remaining = planar_total;
     int tail = 0, ngrow = 0, ncand = 0;
     const int nnz = hdr[5];
-    const bool reg_bins = nnz <= 64;  // one non-empty bin per lane, kept in a register for the whole frame
-    const int mybin = (reg_bins && lane < nnz) ? static_cast<int>(nzlist[lane]) : -1;
+    // up to four non-empty bins per lane, kept in registers for the whole frame
+    const bool reg_bins = nnz <= 256;
+    int mybin[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mybin[q] = (reg_bins && lane + 64 * q < nnz) ? static_cast<int>(nzlist[lane + 64 * q]) : -1;
+    const int reg_sets = (nnz + 63) >> 6;
     // BFS lane constants: lane = (slot, dir); dir 0..3 = U, D, L, R
     const int slot = lane >> 2, dir = lane & 3;
     const int delta = dir == 0 ? -nh : (dir == 1 ? nh : (dir == 2 ? -1 : 1));
@@ -279,7 +283,14 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
       constexpr uint32_t kBinMask = (1u << kBinBits) - 1u;
       uint32_t key = 0;
       if (reg_bins) {
-        if (mybin >= 0) key = (static_cast<uint32_t>(hist[mybin]) << kBinBits) | (kBinMask - static_cast<uint32_t>(mybin));
+        if (mybin[0] >= 0) key = (static_cast<uint32_t>(hist[mybin[0]]) << kBinBits) | (kBinMask - static_cast<uint32_t>(mybin[0]));
+        if (reg_sets > 1) {  // uniform
+#pragma unroll
+          for (int q = 1; q < 4; ++q) {
+            const uint32_t k = mybin[q] >= 0 ? (static_cast<uint32_t>(hist[mybin[q]]) << kBinBits) | (kBinMask - static_cast<uint32_t>(mybin[q])) : 0u;
+            key = k > key ? k : key;
+          }
+        }
       } else {
         for (int t = lane; t < nnz; t += 64) {
           const int b = nzlist[t];
@@ -330,26 +341,61 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
       } else {
         // the bin's list is sorted by (mse, cell id): the seed is its first live entry.  bin_start[bb] only moves
         // forward (a grown cell never comes back), so every list entry is skipped at most once per frame.
+        //
+        // Isolated seeds: on noisy frames two thirds of all grows activate nothing but their seed (no neighbour is both
+        // unassigned and reachable from it).  The chunk scan reads the seed's four neighbour flags along with its own,
+        // and such a grow is committed right here — one queue slot, one grow — without a BFS step.  (Committing several
+        // in a row does not pay: the arg-max keeps the fullest bins level, so it changes bin after almost every grow.)
         int s0 = static_cast<int>(bin_start[bb]);
         const int e = cursor[bb];
+        const bool iso_ok = prm.min_cells > 1 || prm.min_cells < 0;  // a one-cell grow is never a segment candidate
+        bool committed = false;
         while (s0 < e) {
           const int i = s0 + lane;
-          uint32_t c = 0;
-          bool alive = false;
+          uint32_t c = 0, f = 0;
+          bool alive = false, iso = false;
           if (i < e) {
             c = order[i];
-            alive = (flags[c] & F_UNASSIGNED) != 0;
+            const int cc = static_cast<int>(c);
+            const int wU = cc - nh > 0 ? cc - nh : 0, wD = cc + nh < C ? cc + nh : C - 1;
+            const int wL = cc > 0 ? cc - 1 : 0, wR = cc + 1 < C ? cc + 1 : C - 1;
+            f = flags[cc];
+            const uint32_t fU = flags[wU], fD = flags[wD], fL = flags[wL], fR = flags[wR];
+            alive = (f & F_UNASSIGNED) != 0;
+            // a neighbour that is unassigned and whose in-edge bit for this cell's side is set can be activated from
+            // here; clamped (non-existent) neighbours can only make a cell look connected, never isolated
+            const uint32_t out = ((fU & (fU >> 3)) | (fD & (fD >> 2)) | (fL & (fL >> 5)) | (fR & (fR >> 4))) & 1u;
+            iso = alive && out == 0u && iso_ok;
           }
           const unsigned long long am = __ballot(alive);
           if (am) {
             const int first = __builtin_ctzll(am);
             seed = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c), first));
+            committed = ((__ballot(iso) >> first) & 1ull) != 0ull;
+            if (committed && lane == first) {
+              queue[tail] = static_cast<idx_t>(c);
+              qpos[c] = static_cast<idx_t>(tail);
+              flags[c] = static_cast<uint8_t>(f & ~F_UNASSIGNED);
+              grow_start[ngrow] = static_cast<uint32_t>(tail);
+              atomicSub(&hist[bb], 1);
+            }
             s0 += first + 1;
             break;
           }
           s0 += 64;
         }
         if (lane == 0) bin_start[bb] = static_cast<idx_t>(s0 < e ? s0 : e);
+        if (committed) {
+          ++tail;
+          ++ngrow;
+          --remaining;
+          wave_sync();
+          if (DBG) {
+            const unsigned long long tc2 = DPX_STAMP();
+            a_argmax += tb - ta; a_seed += tc2 - tb;
+          }
+          continue;
+        }
       }
       if (seed == 0xFFFFFFFFu) break;
 
