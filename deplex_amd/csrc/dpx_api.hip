@@ -314,7 +314,7 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   rb.merge = h->d_merge; rb.stats = h->d_stats; rb.g_flags = h->d_gflags; rb.g_owner = h->d_gowner;
   rb.g_queue = h->d_gqueue; rb.pcap = h->pcap;
   // the region kernel's tail can write the pixel label map itself (no separate label-expansion launch)
-  const bool fuse_labels = h->regions_tier == 2 && (prm.W & 3) == 0 && !h->opt_nofuse && !skip_l && !skip_r;
+  const bool fuse_labels = (h->regions_tier == 2 || h->regions_tier == 1) && (prm.W & 3) == 0 && !h->opt_nofuse && !skip_l && !skip_r;
   dpx::Regions2Extra rx{};
   rx.mse_c = h->d_mse_c; rx.cand_grow = h->d_cand_grow; rx.dbg = h->d_dbg; rx.lds_img = h->d_lds_img;
   rx.img_bytes = static_cast<int>((h->lds2_bytes + 15) & ~size_t(15));
@@ -324,6 +324,10 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   rx.frames_per_out = per_sub;
   for (int j = 0; j < 8; ++j) rx.labels_out[j] = (fuse_labels && j < nsub) ? subs[j].d_labels : nullptr;
   if (skip_r) {
+  } else if (h->regions_tier == 1 && h->regions_split && !h->d_dbg) {
+    hipLaunchKernelGGL((dpx::k_regions2<1, false, 1>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<1, false, 2>), dim3(batch), dim3(64), h->lds2_bytes, s, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<1, false, 3>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
   } else if (h->regions_tier == 2 && h->d_dbg)
     hipLaunchKernelGGL((dpx::k_regions2<2, true, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
   else if (h->regions_tier == 1 && h->d_dbg)
@@ -331,9 +335,10 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   else if (h->regions_tier == 0 && h->d_dbg)
     hipLaunchKernelGGL((dpx::k_regions2<0, true, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
   else if (h->regions_tier == 2 && h->regions_split) {
+    const bool skip_p2 = skip && std::strchr(skip, '2'), skip_p3 = skip_p2 || (skip && std::strchr(skip, '3'));
     hipLaunchKernelGGL((dpx::k_regions2<2, false, 1>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
-    hipLaunchKernelGGL((dpx::k_regions2<2, false, 2>), dim3(batch), dim3(64), h->lds2_bytes, s, prm, rb, rx);
-    hipLaunchKernelGGL((dpx::k_regions2<2, false, 3>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
+    if (!skip_p2) hipLaunchKernelGGL((dpx::k_regions2<2, false, 2>), dim3(batch), dim3(64), h->lds2_bytes, s, prm, rb, rx);
+    if (!skip_p3) hipLaunchKernelGGL((dpx::k_regions2<2, false, 3>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
   } else if (h->regions_tier == 2)
     hipLaunchKernelGGL((dpx::k_regions2<2, false, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
   else if (h->regions_tier == 1)
@@ -692,17 +697,25 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
         rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
     }
   }
-  if (rc == DPX_OK && h->regions_tier == 2) {
+  if (rc == DPX_OK && (h->regions_tier == 2 || h->regions_tier == 1)) {
     const char* nosplit = std::getenv("DPX_REGIONS_NOSPLIT");
     h->regions_split = !(nosplit && nosplit[0] == '1');
     if (h->regions_split) {
       A(dev_alloc(&h->d_lds_img, B * (((h->lds2_bytes + 15) & ~size_t(15)) / 16)));
       if (rc == DPX_OK && h->lds2_bytes > 48 * 1024) {
         const int lb = static_cast<int>(h->lds2_bytes);
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<2, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lb) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<2, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lb) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<2, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lb) != hipSuccess)
-          rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
+        const void* fns[3];
+        if (h->regions_tier == 2) {
+          fns[0] = reinterpret_cast<const void*>(dpx::k_regions2<2, false, 1>);
+          fns[1] = reinterpret_cast<const void*>(dpx::k_regions2<2, false, 2>);
+          fns[2] = reinterpret_cast<const void*>(dpx::k_regions2<2, false, 3>);
+        } else {
+          fns[0] = reinterpret_cast<const void*>(dpx::k_regions2<1, false, 1>);
+          fns[1] = reinterpret_cast<const void*>(dpx::k_regions2<1, false, 2>);
+          fns[2] = reinterpret_cast<const void*>(dpx::k_regions2<1, false, 3>);
+        }
+        for (const void* fn : fns)
+          if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lb) != hipSuccess) rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
       }
     }
   }

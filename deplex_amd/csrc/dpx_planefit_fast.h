@@ -226,7 +226,12 @@ __device__ __forceinline__ void load_cell_row(const uint16_t* rowp, uint32_t (&w
 // DIAG != 0 are timing-only instantiations (results are garbage): 1 = skip the plane fit / record maths (moments only),
 // 2 = loads + record store only.  Selected with DPX_PF_DIAG for tools/pf_breakdown.py; never used by the product path.
 template <int P, bool FASTDIV, int DIAG = 0>
-__global__ __launch_bounds__(256, DPX_PF_WAVES) void k_planefit_depth(Params prm, const uint16_t* __restrict__ depth,
+#ifdef DPX_PF_VGPR
+#define DPX_PF_VGPR_ATTR __attribute__((amdgpu_num_vgpr(DPX_PF_VGPR)))
+#else
+#define DPX_PF_VGPR_ATTR
+#endif
+__global__ __launch_bounds__(256, DPX_PF_WAVES) DPX_PF_VGPR_ATTR void k_planefit_depth(Params prm, const uint16_t* __restrict__ depth,
                                                             dpx_cell* __restrict__ cells, float rx, float ry) {
   static_assert(P % 2 == 0 && P >= 2, "even patch sizes only");
   constexpr int n = P * P;

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
   constexpr bool GST = TIER == 0;
   using idx_t = typename std::conditional<GST, uint32_t, uint16_t>::type;
   constexpr uint32_t kNoPos = GST ? 0xFFFFFFFFu : 0xFFFFu;
-  static_assert(PHASE == 0 || TIER == 2, "the phase-split launches exist for the all-LDS tier only");
+  static_assert(PHASE == 0 || TIER >= 1, "the phase-split launches need the cell labels in LDS");
 #if DPX_REGIONS_PRIO
   __builtin_amdgcn_s_setprio(DPX_REGIONS_PRIO);  // latency-bound waves: win issue arbitration against co-resident streaming kernels
 #endif
