@@ -70,7 +70,7 @@ struct dpx_handle_s {
   int regions_tier = -1;  // k_regions2<TIER>: 2 all state in LDS, 1 lean, 0 flags in LDS + global queues; -1 = k_regions (v1)
   size_t lds2_bytes = 0;
   // variant switches, read from the environment at create (tests and diagnostics)
-  bool opt_nofuse = false, opt_labels_v1 = false;
+  bool opt_nofuse = false, opt_labels_v1 = false, opt_cloud_nolds = false;
   int opt_csr_chunk = 64;
   int Cpad = 0;                              // tiers 1/0: sort slots per frame (power of two >= C)
   unsigned long long* d_sort_keys = nullptr;  // [B][Cpad]
@@ -204,6 +204,15 @@ void launch_planefit_cloud(dpx_handle h, const dpx::Params& prm, const void* d_i
     const long long waves = static_cast<long long>(prm.batch) * prm.nv * ((prm.nh + 63) / 64);
     const unsigned blocks = static_cast<unsigned>((waves + 3) / 4);
     const float* xyz = static_cast<const float*>(d_in);
+    // LDS-staged form: needs 16-byte aligned row segments (W % 4 == 0 and an aligned cloud)
+    if (!h->opt_cloud_nolds && (prm.W & 3) == 0 && (reinterpret_cast<uintptr_t>(d_in) & 15u) == 0) {
+      switch (prm.P) {
+        case 4: hipLaunchKernelGGL((dpx::k_planefit_cloud_lds<4>), dim3(blocks), dim3(256), 0, s, prm, xyz, d_cells); return;
+        case 8: hipLaunchKernelGGL((dpx::k_planefit_cloud_lds<8>), dim3(blocks), dim3(256), 0, s, prm, xyz, d_cells); return;
+        case 10: hipLaunchKernelGGL((dpx::k_planefit_cloud_lds<10>), dim3(blocks), dim3(256), 0, s, prm, xyz, d_cells); return;
+        default: break;
+      }
+    }
     switch (prm.P) {
       case 4: hipLaunchKernelGGL((dpx::k_planefit_cloud<4>), dim3(blocks), dim3(256), 0, s, prm, xyz, d_cells); return;
       case 8: hipLaunchKernelGGL((dpx::k_planefit_cloud<8>), dim3(blocks), dim3(256), 0, s, prm, xyz, d_cells); return;
@@ -609,6 +618,7 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
   const size_t lds_state = hist_bytes + 6 * C + 16;
   h->opt_nofuse = std::getenv("DPX_NO_FUSED_LABELS") != nullptr;
   h->opt_labels_v1 = std::getenv("DPX_LABELS_V1") != nullptr;
+  h->opt_cloud_nolds = std::getenv("DPX_CLOUD_NOLDS") != nullptr;
   if (const char* e = std::getenv("DPX_CSR_CHUNK")) {  // test hook: force the wide-row walk of the merge phase
     const int v = std::atoi(e);
     h->opt_csr_chunk = v < 0 ? 0 : (v > 64 ? 64 : v);

@@ -34,6 +34,7 @@ namespace dpx {
 #define DPX_PF_WAVES 4
 #endif
 typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x4a8 __attribute__((ext_vector_type(4), aligned(8)));
 typedef uint32_t u32x2a __attribute__((ext_vector_type(2), aligned(4)));
 
 template <bool FASTDIV>
@@ -201,6 +202,33 @@ struct CellAcc {
     const float x = w[3 * J], y = w[3 * J + 1], z = w[3 * J + 2];
     valid_pts += z > 0;
     point<J, KM, TAIL, TAILIDX, K == 0, K == n - 1, I == P / 2>(x, y, z, prm);
+    if ((J % DPX_PF_GROUP) == DPX_PF_GROUP - 1 || J == P - 1) pin();
+  }
+
+  // organised-cloud row with compile-time row residue RM = i & 3; STATIC_I >= 0 as in row<>
+  template <int RM, int STATIC_I>
+  __device__ __forceinline__ void cloud_row_rm(const float (&w)[3 * P], bool is_hrow, const Params& prm) {
+    cloud_row_rm_impl<RM, STATIC_I>(w, is_hrow, prm, std::make_integer_sequence<int, P>{});
+  }
+  template <int RM, int STATIC_I, int... Js>
+  __device__ __forceinline__ void cloud_row_rm_impl(const float (&w)[3 * P], bool is_hrow, const Params& prm, std::integer_sequence<int, Js...>) {
+    (cloud_one_rm<RM, STATIC_I, Js>(w, is_hrow, prm), ...);
+  }
+  template <int RM, int STATIC_I, int J>
+  __device__ __forceinline__ void cloud_one_rm(const float (&w)[3 * P], bool is_hrow, const Params& prm) {
+    constexpr int KM = (RM * P + J) & 7;
+    constexpr int K = STATIC_I >= 0 ? STATIC_I * P + J : -1;
+    constexpr bool TAIL = K >= 0 && K >= A2;
+    constexpr int TAILIDX = TAIL ? K - A2 : 0;
+    const float x = w[3 * J], y = w[3 * J + 1], z = w[3 * J + 2];
+    valid_pts += z > 0;
+    if (STATIC_I >= 0) {
+      point<J, KM, TAIL, TAILIDX, K == 0, K == n - 1, STATIC_I == P / 2>(x, y, z, prm);
+    } else if (is_hrow) {
+      point<J, KM, false, 0, false, false, true>(x, y, z, prm);
+    } else {
+      point<J, KM, false, 0, false, false, false>(x, y, z, prm);
+    }
     if ((J % DPX_PF_GROUP) == DPX_PF_GROUP - 1 || J == P - 1) pin();
   }
 };
@@ -467,5 +495,144 @@ __global__ __launch_bounds__(256, 3) void k_planefit_cloud(Params prm, const flo
   dst[2] = s4[2];
   dst[3] = s4[3];
 }
+
+// ---- organised-cloud input, LDS-staged (W % 4 == 0, 16-byte aligned cloud) ----------------------------------------
+// The per-lane loads of k_planefit_cloud put 64 different cache lines under every load instruction (lane stride 12*P
+// bytes).  Here a wave moves its 64-cell row segment (64 * 12 * P contiguous bytes) straight from global memory into
+// a wave-private LDS buffer with the gfx950 LDS-DMA loads (global_load_lds_dwordx4: lane l delivers bytes
+// [16 l, 16 l + 16) of every KB, no staging registers), and every lane reads its own cell row back (lane stride 12*P
+// bytes: at most 2-way bank conflicts).  The DMA of row i + 1 is in flight while row i is summed.  Everything is
+// branch-free: chunks past the end of a partial strip read a clamped address and land in the padding of the buffer.
+// Rows run as rolled 4-row groups like k_planefit_depth.  Same arithmetic, same results as k_planefit_cloud.
+#ifndef DPX_CLOUD_WAVES
+#define DPX_CLOUD_WAVES 2
+#endif
+typedef __attribute__((address_space(3))) void* dpx_lds_ptr;
+typedef const __attribute__((address_space(1))) void* dpx_glb_ptr;
+
+template <int P>
+struct CloudStage {
+  static constexpr int DWR = 3 * P;                     // dwords per cell row
+  static constexpr int NCH = (DWR * 64 / 4 + 63) / 64;  // 16-byte chunks per lane and row segment
+  static_assert((DWR * 2) % 4 == 0, "segments of an even number of cells end on a 16-byte boundary");
+
+  // asynchronous: completion is observed with s_waitcnt vmcnt(0)
+  static __device__ __forceinline__ void dma(const float* seg, int last_chunk_dw, int lane, float* lds) {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int d = (k * 64 + lane) * 4;
+      __builtin_amdgcn_global_load_lds((dpx_glb_ptr)(seg + (d < last_chunk_dw ? d : last_chunk_dw)), (dpx_lds_ptr)(lds + k * 256), 16, 0, 0);
+    }
+  }
+  static __device__ __forceinline__ void fetch(const float* lds, int lane, float (&w)[DWR]) {
+    const float* rp = lds + lane * DWR;  // 8-byte aligned (DWR even)
+    int d = 0;
+#pragma unroll
+    for (; d + 4 <= DWR; d += 4) {
+      const f32x4a8 v = *reinterpret_cast<const f32x4a8*>(rp + d);
+      w[d] = v.x; w[d + 1] = v.y; w[d + 2] = v.z; w[d + 3] = v.w;
+    }
+    if (d + 2 <= DWR) {
+      const float2 v = *reinterpret_cast<const float2*>(rp + d);
+      w[d] = v.x; w[d + 1] = v.y;
+    }
+  }
+};
+
+// one row: wait for its DMA, read this lane's cell row, start the next row's DMA into the same buffer, sum the row.
+// s_waitcnt immediates (gfx9 encoding): 0x0F70 = vmcnt(0), 0xC07F = lgkmcnt(0).
+#define DPX_CLOUD_STEP(RM, SI, IROW, HASNEXT)                                                                 \
+  {                                                                                                           \
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                                                       \
+    __builtin_amdgcn_wave_barrier();                                                                          \
+    CloudStage<P>::fetch(lds, lane, a);                                                                       \
+    __builtin_amdgcn_s_waitcnt(0xC07F); /* every lane's reads are done before the buffer is overwritten */    \
+    __builtin_amdgcn_wave_barrier();                                                                          \
+    if (HASNEXT) CloudStage<P>::dma(seg0 + static_cast<long long>((IROW) + 1) * row_stride, last_dw, lane, lds); \
+    if ((SI) == 0) acc.vprev = a[3 * (P / 2) + 2]; /* k = P/2 -> (i = 0, j = P/2) */                          \
+    acc.template cloud_row_rm<RM, SI>(a, (IROW) == P / 2, prm);                                               \
+  }
+
+template <int P>
+__global__ __launch_bounds__(256, DPX_CLOUD_WAVES) void k_planefit_cloud_lds(Params prm, const float* __restrict__ xyz, dpx_cell* __restrict__ cells) {
+  static_assert(P % 2 == 0 && P >= 2, "even patch sizes only");
+  constexpr int n = P * P;
+  constexpr int A2 = (n / 8) * 8;
+  constexpr int FULL_A = ((A2 / P) / 4) * 4, FULL_B = ((P - 1) / 4) * 4;
+  constexpr int FULL = FULL_A < FULL_B ? FULL_A : FULL_B;  // rows of the rolled groups, as in k_planefit_depth
+  constexpr int kWaveFloats = CloudStage<P>::NCH * 64 * 4;  // segment buffer of one wave, padded to whole chunks
+  __shared__ __align__(16) float stage_lds[4 * kWaveFloats];
+  const int strips = (prm.nh + 63) >> 6;
+  const int wid = threadIdx.x >> 6;
+  const long long wave = static_cast<long long>(blockIdx.x) * 4 + wid;
+  const int lane = threadIdx.x & 63;
+  const long long per_frame = static_cast<long long>(prm.nv) * strips;
+  if (wave >= per_frame * prm.batch) return;  // wave-uniform: no workgroup barrier is used below
+  const int frame = static_cast<int>(wave / per_frame);
+  const int rem = static_cast<int>(wave - frame * per_frame);
+  const int cr = rem / strips;
+  const int cc0 = (rem - cr * strips) * 64;
+  const int ncell = (prm.nh - cc0) < 64 ? (prm.nh - cc0) : 64;
+  const int last_dw = ncell * 3 * P - 4;  // first dword of the segment's last whole chunk
+  const long long row_stride = 3ll * prm.W;
+  const float* seg0 = xyz + 3ll * (static_cast<long long>(frame) * prm.N + static_cast<long long>(cr) * P * prm.W + static_cast<long long>(cc0) * P);
+  float* lds = stage_lds + wid * kWaveFloats;
+
+  CellAcc<P, false> acc;
+  acc.init();
+  float a[3 * P];
+  CloudStage<P>::dma(seg0, last_dw, lane, lds);
+  if (FULL >= 4) {
+    DPX_CLOUD_STEP(0, 0, 0, true)
+    DPX_CLOUD_STEP(1, 1, 1, true)
+    DPX_CLOUD_STEP(2, 2, 2, true)
+    DPX_CLOUD_STEP(3, 3, 3, true)
+#pragma nounroll
+    for (int g = 4; g < FULL; g += 4) {
+      DPX_CLOUD_STEP(0, -1, g + 0, true)
+      DPX_CLOUD_STEP(1, -1, g + 1, true)
+      DPX_CLOUD_STEP(2, -1, g + 2, true)
+      DPX_CLOUD_STEP(3, -1, g + 3, true)
+    }
+  }
+  {
+    constexpr int R0 = FULL >= 4 ? FULL : 0;
+    static_assert(P - R0 <= 4, "at most one partial group after the rolled loop");
+    if (R0 + 0 < P) DPX_CLOUD_STEP((R0 + 0) & 3, (R0 + 0 < P ? R0 + 0 : 0), R0 + 0, R0 + 1 < P)
+    if (R0 + 1 < P) DPX_CLOUD_STEP((R0 + 1) & 3, (R0 + 1 < P ? R0 + 1 : 0), R0 + 1, R0 + 2 < P)
+    if (R0 + 2 < P) DPX_CLOUD_STEP((R0 + 2) & 3, (R0 + 2 < P ? R0 + 2 : 0), R0 + 2, R0 + 3 < P)
+    if (R0 + 3 < P) DPX_CLOUD_STEP((R0 + 3) & 3, (R0 + 3 < P ? R0 + 3 : 0), R0 + 3, R0 + 4 < P)
+  }
+  if (lane >= ncell) return;  // helper lanes of a partial strip only moved data
+
+  const int cc = cc0 + lane;
+  if (A2 > 0 && n == A2) { acc.sx.fold(); acc.sy.fold(); acc.sz.fold(); }
+  float sum[3], pp[6];
+  sum[0] = (acc.sx.c[0] + acc.sx.c[2]) + (acc.sx.c[1] + acc.sx.c[3]);
+  sum[1] = (acc.sy.c[0] + acc.sy.c[2]) + (acc.sy.c[1] + acc.sy.c[3]);
+  sum[2] = (acc.sz.c[0] + acc.sz.c[2]) + (acc.sz.c[1] + acc.sz.c[3]);
+  pp[0] = acc.xx; pp[1] = acc.xy; pp[2] = acc.xz; pp[3] = acc.yy; pp[4] = acc.yz; pp[5] = acc.zz;
+  const bool cont = (acc.hdisc < prm.max_disc) && (acc.vdisc < prm.max_disc);
+  const bool valid = prm.valid_thr >= 0 && static_cast<long long>(acc.valid_pts) >= prm.valid_thr && cont;
+  dpx_cell rec;
+  if (valid) {
+    finish_cell(prm, n, sum, pp, acc.fx0 - acc.lx, acc.fy0 - acc.ly, acc.fz0 - acc.lz, true, rec);
+  } else {
+    rec.sum[0] = rec.sum[1] = rec.sum[2] = 0.f;
+    rec.pp[0] = rec.pp[1] = rec.pp[2] = rec.pp[3] = rec.pp[4] = rec.pp[5] = 0.f;
+    rec.normal[0] = rec.normal[1] = rec.normal[2] = 0.f;
+    rec.d = 0.f;
+    rec.mse = 3.402823466e+38f;
+    rec.tol = 0.f;
+    rec.info = 0u;
+  }
+  float4* dst = reinterpret_cast<float4*>(cells + static_cast<long long>(frame) * prm.C + static_cast<long long>(cr) * prm.nh + cc);
+  const float4* s4 = reinterpret_cast<const float4*>(&rec);
+  dst[0] = s4[0];
+  dst[1] = s4[1];
+  dst[2] = s4[2];
+  dst[3] = s4[3];
+}
+#undef DPX_CLOUD_STEP
 
 }  // namespace dpx

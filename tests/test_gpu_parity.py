@@ -165,15 +165,30 @@ def test_patch_sizes(D, oracle, patch):
     full_compare(D, oracle, depth, synth.intrinsics_for(240, 320), oracle.default_config(patch_size=patch))
 
 
-def test_cloud_input_fast_path(D, oracle, tum_depth):
-    """process(pcd) / process_pcd_batch through the tuned organised-cloud kernel (P = 10, 4, 8), including the
-    reference's float64 Python-test cloud and a cloud that is NOT a back-projection (arbitrary xyz)."""
+@pytest.mark.parametrize("env", [None, "DPX_CLOUD_NOLDS"])
+def test_cloud_input_fast_path(D, oracle, tum_depth, env):
+    """process(pcd) / process_pcd_batch through the tuned organised-cloud kernels (P = 10, 4, 8; LDS-staged row
+    segments by default, per-lane loads with DPX_CLOUD_NOLDS), including partial 64-cell strips and a cloud that is NOT
+    a back-projection (arbitrary xyz)."""
+    if env:
+        os.environ[env] = "1"
+    try:
+        _cloud_input_cases(D, oracle)
+    finally:
+        if env:
+            del os.environ[env]
+
+
+def _cloud_input_cases(D, oracle):
     K = synth.read_K(synth.TUM_K)
     intr = tuple(float(v) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2]))
     full_compare(D, oracle, synth.tum_stream(3), intr, oracle.default_config(), xyz_api=True)
     for patch in (4, 8, 10):
         depth = synth.synth_batch(2, 240, 320, seed0=40 + patch)
         full_compare(D, oracle, depth, synth.intrinsics_for(240, 320), oracle.default_config(patch_size=patch), xyz_api=True)
+    for (h, w, patch) in [(60, 1280, 10), (40, 660, 10), (24, 132, 4), (32, 1048, 8)]:  # 2 strips; 64 + 2 cells; 33 cells; 131 cells
+        depth = synth.synth_batch(2, h, w, seed0=60)
+        full_compare(D, oracle, depth, synth.intrinsics_for(h, w), oracle.default_config(patch_size=patch), xyz_api=True)
     rng = np.random.default_rng(5)
     h, w = 120, 160
     base = oracle.backproject(synth.synth_depth(h, w, seed=3), *[np.float32(v) for v in synth.intrinsics_for(h, w)])
