@@ -539,18 +539,21 @@ struct CloudStage {
   }
 };
 
-// one row: wait for its DMA, read this lane's cell row, start the next row's DMA into the same buffer, sum the row.
-// s_waitcnt immediates (gfx9 encoding): 0x0F70 = vmcnt(0), 0xC07F = lgkmcnt(0).
-#define DPX_CLOUD_STEP(RM, SI, IROW, HASNEXT)                                                                 \
-  {                                                                                                           \
-    __builtin_amdgcn_s_waitcnt(0x0F70);                                                                       \
-    __builtin_amdgcn_wave_barrier();                                                                          \
-    CloudStage<P>::fetch(lds, lane, a);                                                                       \
-    __builtin_amdgcn_s_waitcnt(0xC07F); /* every lane's reads are done before the buffer is overwritten */    \
-    __builtin_amdgcn_wave_barrier();                                                                          \
-    if (HASNEXT) CloudStage<P>::dma(seg0 + static_cast<long long>((IROW) + 1) * row_stride, last_dw, lane, lds); \
-    if ((SI) == 0) acc.vprev = a[3 * (P / 2) + 2]; /* k = P/2 -> (i = 0, j = P/2) */                          \
-    acc.template cloud_row_rm<RM, SI>(a, (IROW) == P / 2, prm);                                               \
+// one row: wait for its DMA (the next row's may stay in flight), read this lane's cell row, start the DMA of the row
+// after next into the same buffer, sum the row.  Two buffers per wave: rows alternate between them.
+// s_waitcnt immediates (gfx9 encoding): 0x0F70 | n = vmcnt(n) for n < 16, 0xC07F = lgkmcnt(0).
+#define DPX_CLOUD_STEP(RM, SI, IROW, HASNEXT, HASNEXT2)                                                        \
+  {                                                                                                            \
+    if (HASNEXT) __builtin_amdgcn_s_waitcnt(0x0F70 | CloudStage<P>::NCH);                                      \
+    else __builtin_amdgcn_s_waitcnt(0x0F70);                                                                   \
+    __builtin_amdgcn_wave_barrier();                                                                           \
+    float* buf_ = lds + ((RM) & 1) * kWaveFloats;                                                              \
+    CloudStage<P>::fetch(buf_, lane, a);                                                                       \
+    __builtin_amdgcn_s_waitcnt(0xC07F); /* every lane's reads are done before the buffer is overwritten */     \
+    __builtin_amdgcn_wave_barrier();                                                                           \
+    if (HASNEXT2) CloudStage<P>::dma(seg0 + static_cast<long long>((IROW) + 2) * row_stride, last_dw, lane, buf_); \
+    if ((SI) == 0) acc.vprev = a[3 * (P / 2) + 2]; /* k = P/2 -> (i = 0, j = P/2) */                           \
+    acc.template cloud_row_rm<RM, SI>(a, (IROW) == P / 2, prm);                                                \
   }
 
 template <int P>
@@ -561,7 +564,8 @@ __global__ __launch_bounds__(256, DPX_CLOUD_WAVES) void k_planefit_cloud_lds(Par
   constexpr int FULL_A = ((A2 / P) / 4) * 4, FULL_B = ((P - 1) / 4) * 4;
   constexpr int FULL = FULL_A < FULL_B ? FULL_A : FULL_B;  // rows of the rolled groups, as in k_planefit_depth
   constexpr int kWaveFloats = CloudStage<P>::NCH * 64 * 4;  // segment buffer of one wave, padded to whole chunks
-  __shared__ __align__(16) float stage_lds[4 * kWaveFloats];
+  static_assert(CloudStage<P>::NCH < 16, "vmcnt immediate");
+  __shared__ __align__(16) float stage_lds[4 * 2 * kWaveFloats];
   const int strips = (prm.nh + 63) >> 6;
   const int wid = threadIdx.x >> 6;
   const long long wave = static_cast<long long>(blockIdx.x) * 4 + wid;
@@ -576,32 +580,33 @@ __global__ __launch_bounds__(256, DPX_CLOUD_WAVES) void k_planefit_cloud_lds(Par
   const int last_dw = ncell * 3 * P - 4;  // first dword of the segment's last whole chunk
   const long long row_stride = 3ll * prm.W;
   const float* seg0 = xyz + 3ll * (static_cast<long long>(frame) * prm.N + static_cast<long long>(cr) * P * prm.W + static_cast<long long>(cc0) * P);
-  float* lds = stage_lds + wid * kWaveFloats;
+  float* lds = stage_lds + wid * 2 * kWaveFloats;
 
   CellAcc<P, false> acc;
   acc.init();
   float a[3 * P];
   CloudStage<P>::dma(seg0, last_dw, lane, lds);
+  if (P > 1) CloudStage<P>::dma(seg0 + row_stride, last_dw, lane, lds + kWaveFloats);
   if (FULL >= 4) {
-    DPX_CLOUD_STEP(0, 0, 0, true)
-    DPX_CLOUD_STEP(1, 1, 1, true)
-    DPX_CLOUD_STEP(2, 2, 2, true)
-    DPX_CLOUD_STEP(3, 3, 3, true)
+    DPX_CLOUD_STEP(0, 0, 0, true, 2 < P)
+    DPX_CLOUD_STEP(1, 1, 1, true, 3 < P)
+    DPX_CLOUD_STEP(2, 2, 2, true, 4 < P)
+    DPX_CLOUD_STEP(3, 3, 3, 4 < P, 5 < P)
 #pragma nounroll
-    for (int g = 4; g < FULL; g += 4) {
-      DPX_CLOUD_STEP(0, -1, g + 0, true)
-      DPX_CLOUD_STEP(1, -1, g + 1, true)
-      DPX_CLOUD_STEP(2, -1, g + 2, true)
-      DPX_CLOUD_STEP(3, -1, g + 3, true)
+    for (int g = 4; g < FULL; g += 4) {  // rows below FULL <= P - 2: both following rows exist
+      DPX_CLOUD_STEP(0, -1, g + 0, true, true)
+      DPX_CLOUD_STEP(1, -1, g + 1, true, true)
+      DPX_CLOUD_STEP(2, -1, g + 2, true, true)
+      DPX_CLOUD_STEP(3, -1, g + 3, true, true)
     }
   }
   {
     constexpr int R0 = FULL >= 4 ? FULL : 0;
     static_assert(P - R0 <= 4, "at most one partial group after the rolled loop");
-    if (R0 + 0 < P) DPX_CLOUD_STEP((R0 + 0) & 3, (R0 + 0 < P ? R0 + 0 : 0), R0 + 0, R0 + 1 < P)
-    if (R0 + 1 < P) DPX_CLOUD_STEP((R0 + 1) & 3, (R0 + 1 < P ? R0 + 1 : 0), R0 + 1, R0 + 2 < P)
-    if (R0 + 2 < P) DPX_CLOUD_STEP((R0 + 2) & 3, (R0 + 2 < P ? R0 + 2 : 0), R0 + 2, R0 + 3 < P)
-    if (R0 + 3 < P) DPX_CLOUD_STEP((R0 + 3) & 3, (R0 + 3 < P ? R0 + 3 : 0), R0 + 3, R0 + 4 < P)
+    if (R0 + 0 < P) DPX_CLOUD_STEP((R0 + 0) & 3, (R0 + 0 < P ? R0 + 0 : 0), R0 + 0, R0 + 1 < P, R0 + 2 < P)
+    if (R0 + 1 < P) DPX_CLOUD_STEP((R0 + 1) & 3, (R0 + 1 < P ? R0 + 1 : 0), R0 + 1, R0 + 2 < P, R0 + 3 < P)
+    if (R0 + 2 < P) DPX_CLOUD_STEP((R0 + 2) & 3, (R0 + 2 < P ? R0 + 2 : 0), R0 + 2, R0 + 3 < P, R0 + 4 < P)
+    if (R0 + 3 < P) DPX_CLOUD_STEP((R0 + 3) & 3, (R0 + 3 < P ? R0 + 3 : 0), R0 + 3, R0 + 4 < P, R0 + 5 < P)
   }
   if (lane >= ncell) return;  // helper lanes of a partial strip only moved data
 
