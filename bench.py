@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--roofline-iters", type=int, default=50)
     ap.add_argument("--no-cloud-roofline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="only the stand-alone plane-fit series (for rocprofv3 --stats / --pmc runs)")
+    ap.add_argument("--roofline-input", choices=("depth", "cloud"), default="depth", help="input form of the --roofline-only series")
     ap.add_argument("--workload", default="tum_stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-frames", type=int, default=4)
@@ -150,11 +151,18 @@ def main():
 
     if args.roofline_only:
         rstream = torch.cuda.Stream(device=dev)
-        exs[0].time_planefit(d_depth.data_ptr(), 0, B, *intr, 5, rstream.cuda_stream)
-        ms = exs[0].time_planefit(d_depth.data_ptr(), 0, B, *intr, args.roofline_iters, rstream.cuda_stream)
-        by = exs[0].planefit_bytes(0, B)
-        print(json.dumps({"roofline_only": True, "kernel": "k_planefit_depth", "batch": B, "workload": args.workload,
-                          "avg_launch_ms": round(ms, 4), "bytes_per_launch": by,
+        cloud = args.roofline_input == "cloud"
+        if cloud:
+            from oracle import oracle as O  # back-projection of the bench frames (input preparation only)
+            xyz = np.stack([O.backproject(f, *[np.float32(v) for v in intr]) for f in depth])
+            d_in = torch.from_numpy(xyz).to(dev)
+        else:
+            d_in = d_depth
+        exs[0].time_planefit(d_in.data_ptr(), int(cloud), B, *intr, 5, rstream.cuda_stream)
+        ms = exs[0].time_planefit(d_in.data_ptr(), int(cloud), B, *intr, args.roofline_iters, rstream.cuda_stream)
+        by = exs[0].planefit_bytes(int(cloud), B)
+        print(json.dumps({"roofline_only": True, "kernel": "k_planefit_cloud_lds" if cloud else "k_planefit_depth", "batch": B,
+                          "workload": args.workload, "avg_launch_ms": round(ms, 4), "bytes_per_launch": by,
                           "achieved_GBps": round(by / (ms * 1e-3) / 1e9, 1), "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}))
         return
     elapsed = timed_region(step, sync, barrier, args.steps, args.warmup)
@@ -205,13 +213,14 @@ def main():
         pf_ms = pf_alone_ms
         achieved = pf_bytes / (pf_ms * 1e-3) / 1e9 if pf_ms > 0 else 0.0
         in_pipe = pf_bytes / (kms["planefit"] * 1e-3) / 1e9 if kms["planefit"] > 0 else 0.0
-        traffic = None
+        traffic = cloud_traffic = None
         tfile = ROOT / "profiles" / "planefit_traffic.json"
         if tfile.exists():
             try:
                 tj = json.loads(tfile.read_text())
                 if tj.get("batch") == B and tj.get("workload") == args.workload:
                     traffic = tj.get("hbm_bytes_per_launch")
+                cloud_traffic = tj.get("cloud", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -235,10 +244,10 @@ def main():
         }
         if cloud_ms:
             cb = exs[0].planefit_bytes(1, B)
-            out["roofline_cloud_input"] = {"kernel": "k_planefit_cloud (organised xyz cloud -> per-cell moments + eigen plane fit)",
+            out["roofline_cloud_input"] = {"kernel": "k_planefit_cloud_lds (organised xyz cloud -> per-cell moments + eigen plane fit)",
                                            "bound": "hbm", "achieved": round(cb / (cloud_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": round(cb / (cloud_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                           "bytes_per_launch": cb, "avg_launch_ms": round(cloud_ms, 4)}
+                                           "traffic": cloud_traffic, "bytes_per_launch": cb, "avg_launch_ms": round(cloud_ms, 4)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(depth, intr, min(16, os.cpu_count() or 1))  # the box's CPU share for one GPU
         print(json.dumps(out), flush=True)
