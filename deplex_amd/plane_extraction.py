@@ -66,6 +66,7 @@ class PlaneExtractor:
                  device: int = 0):
         self._h = C.c_void_p()
         cfg = config if config is not None else Config()
+        self.config = cfg
         self.image_height, self.image_width = int(image_height), int(image_width)
         self.max_batch = int(max_batch)
         self.device = int(device)
@@ -168,6 +169,34 @@ class PlaneExtractor:
         out = np.zeros(1, dtype=_capi.STATS_DTYPE)
         _capi.check(_capi.lib().dpx_get_frame_stats(self._h, frame, out.ctypes.data))
         return out[0]
+
+    # ---- the reference's DEBUG_DEPLEX stage dumps (plane_extractor.cpp:204-263, 514-549) ---------------------
+    def dump_debug(self, directory, labels, frame: int = 0) -> dict:
+        """Writes, for one frame of the last call, the CSV files a DEBUG_DEPLEX build of the reference leaves in its
+        working directory, byte-compatible in layout, so the two can be diffed stage by stage:
+        dbg_1_planar_cells.csv (H x W, cell id inside planar cells, else 0), dbg_3_labels.csv (label map before
+        refinement = merged cell labels expanded), dbg_4_refined_labels.csv (only with ransac_refinement: the final
+        map).  `labels` is that frame's output of process*().  Returns the reference's three [DebugInfo] counters."""
+        from pathlib import Path
+        d = Path(directory)
+        d.mkdir(parents=True, exist_ok=True)
+        h, w, P = self.image_height, self.image_width, max(int(self.config.patch_size), 1)
+        P = min(P, h, w)
+        cells = self.cells(frame)
+        planar = (cells["info"] & 2) != 0
+        img = np.zeros((h, w), dtype=np.int32)
+        ids = np.where(planar, np.arange(self.nh * self.nv, dtype=np.int32), 0).reshape(self.nv, self.nh)
+        img[: self.nv * P, : self.nh * P] = np.repeat(np.repeat(ids, P, axis=0), P, axis=1)
+        np.savetxt(d / "dbg_1_planar_cells.csv", img, fmt="%d", delimiter=",")
+        merged = np.zeros((h, w), dtype=np.int32)
+        merged[: self.nv * P, : self.nh * P] = np.repeat(np.repeat(self.cell_labels(frame), P, axis=0), P, axis=1)
+        np.savetxt(d / "dbg_3_labels.csv", merged, fmt="%d", delimiter=",")
+        final = np.asarray(labels, dtype=np.int32).reshape(h, w)
+        if self.config.ransac_refinement:
+            np.savetxt(d / "dbg_4_refined_labels.csv", final, fmt="%d", delimiter=",")
+        planes = self.planes(frame)
+        return {"planar_cells": int(planar.sum()), "plane_segments": int(len(planes)),
+                "planes_after_merge": int(len(np.unique(planes["merge_label"]))) if len(planes) else 0}
 
     # ---- measurement ------------------------------------------------------------------------------------
     def set_profiling(self, enable: bool) -> None:

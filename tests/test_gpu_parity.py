@@ -415,6 +415,31 @@ def test_multistream_pipeline(D, oracle):
         del pipe
 
 
+def test_debug_dumps(D, oracle, tum_depth, tmp_path):
+    """The DEBUG_DEPLEX stage CSVs of the reference (plane_extractor.cpp:204-263): same names, same layout."""
+    K = synth.read_K(synth.TUM_K)
+    intr = tuple(float(v) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2]))
+    for refine in (False, True):
+        cfg = D.Config()
+        cfg.ransac_refinement = refine
+        ex = D.PlaneExtractor(480, 640, cfg)
+        labels = ex.process_depth_batch(tum_depth[None], *intr)[0]
+        info = ex.dump_debug(tmp_path / str(refine), labels)
+        assert info == {"planar_cells": int(ex.frame_stats(0)["planar_cells"]), "plane_segments": 34,
+                        "planes_after_merge": len(np.unique(labels)) - 1 if not refine else info["planes_after_merge"]}
+        d1 = np.loadtxt(tmp_path / str(refine) / "dbg_1_planar_cells.csv", delimiter=",", dtype=np.int64)
+        d3 = np.loadtxt(tmp_path / str(refine) / "dbg_3_labels.csv", delimiter=",", dtype=np.int64)
+        assert d1.shape == d3.shape == (480, 640)
+        assert d1[5, 15] in (0, 1) and set(np.unique(d1[::10, ::10] // 1)) <= set(range(64 * 48))
+        assert (d1[0:10, 10:20] == d1[0, 10]).all()
+        if refine:
+            d4 = np.loadtxt(tmp_path / str(refine) / "dbg_4_refined_labels.csv", delimiter=",", dtype=np.int64)
+            assert np.array_equal(d4.ravel(), labels) and not np.array_equal(d3.ravel(), labels)
+            assert ((d4 == d3) | (d4 == 0)).all()  # refinement only clears labels
+        else:
+            assert np.array_equal(d3.ravel(), labels) and not (tmp_path / str(refine) / "dbg_4_refined_labels.csv").exists()
+
+
 def test_ransac_refinement_parity(D, oracle, tum_depth, icl_depth):
     """refineLabels (plane_extractor.cpp:472-509) on the device: same label maps as the oracle (which uses
     std::mt19937 / std::uniform_int_distribution directly), through the depth and the cloud entry points, plus the
