@@ -68,7 +68,9 @@ struct dpx_handle_s {
   float* d_mse_c = nullptr;
   uint32_t* d_cand_grow = nullptr;
   int regions_tier = -1;  // k_regions2<TIER>: 2 all state in LDS, 1 lean, 0 flags in LDS + global queues; -1 = k_regions (v1)
-  size_t lds2_bytes = 0;
+  size_t lds2_bytes = 0;                     // single-launch form: image + the larger of staging / sort keys
+  size_t lds2_img = 0, lds2_p1 = 0, lds2_p2 = 0, lds2_p3 = 0;  // split form: image, and the three launches' allocations
+  int sort_pad = 0;                          // tier 2: slots of the in-LDS seed-list sort (power of two >= C)
   // variant switches, read from the environment at create (tests and diagnostics)
   bool opt_nofuse = false, opt_labels_v1 = false, opt_cloud_nolds = false;
   int opt_csr_chunk = 64;
@@ -326,7 +328,8 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   const bool fuse_labels = (h->regions_tier == 2 || h->regions_tier == 1) && (prm.W & 3) == 0 && !h->opt_nofuse && !skip_l && !skip_r;
   dpx::Regions2Extra rx{};
   rx.mse_c = h->d_mse_c; rx.cand_grow = h->d_cand_grow; rx.dbg = h->d_dbg; rx.lds_img = h->d_lds_img;
-  rx.img_bytes = static_cast<int>((h->lds2_bytes + 15) & ~size_t(15));
+  rx.img_bytes = static_cast<int>(h->lds2_img);
+  rx.sort_pad = h->sort_pad;
   rx.csr_chunk = h->opt_csr_chunk;
   rx.bin_off = h->d_bin_off;
   rx.g_qpos = h->d_gqpos;
@@ -334,9 +337,9 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   for (int j = 0; j < 8; ++j) rx.labels_out[j] = (fuse_labels && j < nsub) ? subs[j].d_labels : nullptr;
   if (skip_r) {
   } else if (h->regions_tier == 1 && h->regions_split && !h->d_dbg) {
-    hipLaunchKernelGGL((dpx::k_regions2<1, false, 1>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
-    hipLaunchKernelGGL((dpx::k_regions2<1, false, 2>), dim3(batch), dim3(64), h->lds2_bytes, s, prm, rb, rx);
-    hipLaunchKernelGGL((dpx::k_regions2<1, false, 3>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<1, false, 1>), dim3(batch), dim3(dpx::kRT), h->lds2_p1, s, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<1, false, 2>), dim3(batch), dim3(64), h->lds2_p2, s, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<1, false, 3>), dim3(batch), dim3(dpx::kRT), h->lds2_p3, s, prm, rb, rx);
   } else if (h->regions_tier == 2 && h->d_dbg)
     hipLaunchKernelGGL((dpx::k_regions2<2, true, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
   else if (h->regions_tier == 1 && h->d_dbg)
@@ -345,9 +348,9 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
     hipLaunchKernelGGL((dpx::k_regions2<0, true, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
   else if (h->regions_tier == 2 && h->regions_split) {
     const bool skip_p2 = skip && std::strchr(skip, '2'), skip_p3 = skip_p2 || (skip && std::strchr(skip, '3'));
-    hipLaunchKernelGGL((dpx::k_regions2<2, false, 1>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
-    if (!skip_p2) hipLaunchKernelGGL((dpx::k_regions2<2, false, 2>), dim3(batch), dim3(64), h->lds2_bytes, s, prm, rb, rx);
-    if (!skip_p3) hipLaunchKernelGGL((dpx::k_regions2<2, false, 3>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<2, false, 1>), dim3(batch), dim3(dpx::kRT), h->lds2_p1, s, prm, rb, rx);
+    if (!skip_p2) hipLaunchKernelGGL((dpx::k_regions2<2, false, 2>), dim3(batch), dim3(64), h->lds2_p2, s, prm, rb, rx);
+    if (!skip_p3) hipLaunchKernelGGL((dpx::k_regions2<2, false, 3>), dim3(batch), dim3(dpx::kRT), h->lds2_p3, s, prm, rb, rx);
   } else if (h->regions_tier == 2)
     hipLaunchKernelGGL((dpx::k_regions2<2, false, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
   else if (h->regions_tier == 1)
@@ -630,25 +633,39 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
                                                       ? static_cast<long long>(C)
                                                       : static_cast<long long>(C) / cfg->min_region_growing_cells_activated));
   {
-    // region-growing kernel tier: everything in LDS (13 B/cell), lean (7 B/cell), flag byte only (1 B/cell, queues in
-    // global memory), or the v1 kernel
-    const size_t fixed = 192 + static_cast<size_t>(2 * nb) * 4 + static_cast<size_t>(nb + 2) * 2 + static_cast<size_t>(dpx::kStageFloats) * 4 + 16;
-    const size_t fixed0 = 192 + static_cast<size_t>(2 * nb) * 4 + static_cast<size_t>(nb + 2) * 4 + static_cast<size_t>(dpx::kStageFloats) * 4 + 16;
+    // region-growing kernel tier (dpx_regions2.h): 2 = everything in LDS (9 B/cell + 8 B/sort slot while preparing),
+    // 1 = lean (7 B/cell), 0 = flag byte only (1 B/cell, queues in global memory), else the v1 kernel
     const char* v1 = std::getenv("DPX_REGIONS_V1");
     const char* lean = std::getenv("DPX_REGIONS_LEAN");
     const char* gst = std::getenv("DPX_REGIONS_GSTATE");
     const bool want_lean = lean && lean[0] == '1', want_gst = gst && gst[0] == '1';
+    const size_t stage_bytes = static_cast<size_t>(dpx::kStageFloats) * 4;
+    size_t pad2 = 1;
+    while (pad2 < C) pad2 <<= 1;
     h->regions_tier = -1;
     if (!(v1 && v1[0] == '1') && !(force && force[0] == '1') && nb < 4600) {
-      if (C < 65000 && fixed + 13 * C <= kLdsLimit && !want_lean && !want_gst) {
+      const int Ci = static_cast<int>(C), nbi = static_cast<int>(nb);
+      const size_t img2 = dpx::r2_layout(2, Ci, nbi).image_end, img1 = dpx::r2_layout(1, Ci, nbi).image_end,
+                   img0 = dpx::r2_layout(0, Ci, nbi).image_end;
+      if (C < 65000 && img2 + std::max(stage_bytes, 8 * pad2) <= kLdsLimit && !want_lean && !want_gst) {
         h->regions_tier = 2;
-        h->lds2_bytes = fixed + 13 * C;
-      } else if (C < 65000 && fixed + 7 * C <= kLdsLimit && !want_gst) {
+        h->sort_pad = static_cast<int>(pad2);
+        h->lds2_img = img2;
+        h->lds2_p1 = img2 + 8 * pad2;
+        h->lds2_p2 = img2;
+        h->lds2_p3 = img2 + stage_bytes;
+        h->lds2_bytes = img2 + std::max(stage_bytes, 8 * pad2);
+      } else if (C < 65000 && img1 + stage_bytes <= kLdsLimit && !want_gst) {
         h->regions_tier = 1;
-        h->lds2_bytes = fixed + 7 * C;
-      } else if (C < (size_t(1) << dpx::kKeyCellBits) && fixed0 + C <= kLdsLimit) {
+        h->lds2_img = img1;
+        h->lds2_p1 = img1;
+        h->lds2_p2 = img1;
+        h->lds2_p3 = img1 + stage_bytes;
+        h->lds2_bytes = img1 + stage_bytes;
+      } else if (C < (size_t(1) << dpx::kKeyCellBits) && img0 + stage_bytes <= kLdsLimit) {
         h->regions_tier = 0;
-        h->lds2_bytes = fixed0 + C;
+        h->lds2_img = img0;
+        h->lds2_bytes = img0 + stage_bytes;
       }
     }
     if (h->regions_tier == 1 || h->regions_tier == 0) {
@@ -711,22 +728,22 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
     const char* nosplit = std::getenv("DPX_REGIONS_NOSPLIT");
     h->regions_split = !(nosplit && nosplit[0] == '1');
     if (h->regions_split) {
-      A(dev_alloc(&h->d_lds_img, B * (((h->lds2_bytes + 15) & ~size_t(15)) / 16)));
-      if (rc == DPX_OK && h->lds2_bytes > 48 * 1024) {
-        const int lb = static_cast<int>(h->lds2_bytes);
-        const void* fns[3];
-        if (h->regions_tier == 2) {
-          fns[0] = reinterpret_cast<const void*>(dpx::k_regions2<2, false, 1>);
-          fns[1] = reinterpret_cast<const void*>(dpx::k_regions2<2, false, 2>);
-          fns[2] = reinterpret_cast<const void*>(dpx::k_regions2<2, false, 3>);
-        } else {
-          fns[0] = reinterpret_cast<const void*>(dpx::k_regions2<1, false, 1>);
-          fns[1] = reinterpret_cast<const void*>(dpx::k_regions2<1, false, 2>);
-          fns[2] = reinterpret_cast<const void*>(dpx::k_regions2<1, false, 3>);
-        }
-        for (const void* fn : fns)
-          if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lb) != hipSuccess) rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
+      A(dev_alloc(&h->d_lds_img, B * (h->lds2_img / 16)));
+      const void* fns[3];
+      if (h->regions_tier == 2) {
+        fns[0] = reinterpret_cast<const void*>(dpx::k_regions2<2, false, 1>);
+        fns[1] = reinterpret_cast<const void*>(dpx::k_regions2<2, false, 2>);
+        fns[2] = reinterpret_cast<const void*>(dpx::k_regions2<2, false, 3>);
+      } else {
+        fns[0] = reinterpret_cast<const void*>(dpx::k_regions2<1, false, 1>);
+        fns[1] = reinterpret_cast<const void*>(dpx::k_regions2<1, false, 2>);
+        fns[2] = reinterpret_cast<const void*>(dpx::k_regions2<1, false, 3>);
       }
+      const size_t need[3] = {h->lds2_p1, h->lds2_p2, h->lds2_p3};
+      for (int i = 0; i < 3 && rc == DPX_OK; ++i)
+        if (need[i] > 48 * 1024 &&
+            hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(need[i])) != hipSuccess)
+          rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
     }
   }
   if (rc == DPX_OK && h->regions_tier >= 0 && h->lds2_bytes > 48 * 1024) {

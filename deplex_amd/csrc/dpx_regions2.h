@@ -17,6 +17,7 @@
 #pragma once
 #include <type_traits>
 
+#include "dpx_binsort.h"
 #include "dpx_regions.h"
 
 namespace dpx {
@@ -58,6 +59,33 @@ constexpr int kRW = DPX_RT / 64;   // waves
 constexpr int kStage = 32;         // entries of the per-wave staging buffer of the accumulation phase
 constexpr int kStageFloats = (kRW * kStage * 9 > 2304) ? kRW * kStage * 9 : 2304;  // the merge phase needs 2304 words
 
+// LDS image of a frame's region-growing state (byte offsets), shared by the device code and the host's size
+// computation.  Everything up to image_end is handed from launch to launch in split mode; the float staging buffer
+// of the tail phases and the sort keys of the tier-2 preparation live behind it and are phase-local.
+struct R2Layout {
+  uint32_t hist, cursor, bin_start, nzlist, flags, qpos, queue, order, binof, image_end;
+};
+__host__ __device__ inline R2Layout r2_layout(int tier, int C, int nb) {
+  R2Layout L{};
+  uint32_t o = 192;  // header words
+  L.hist = o; o += 4u * nb;
+  L.cursor = o; o += 4u * nb;
+  L.bin_start = o; o += static_cast<uint32_t>(nb + 2) * (tier == 0 ? 4u : 2u);
+  o = (o + 3u) & ~3u;
+  L.nzlist = o; o += 2u * nb;
+  o = (o + 3u) & ~3u;
+  L.flags = o; o += static_cast<uint32_t>(C);
+  o = (o + 3u) & ~3u;
+  if (tier >= 1) {
+    L.qpos = o; o += 2u * C;
+    L.queue = o; o += 2u * C;
+    L.order = o; o += 2u * C;
+  }
+  if (tier == 2) { L.binof = o; o += 2u * C; }
+  L.image_end = (o + 15u) & ~15u;
+  return L;
+}
+
 struct Regions2Extra {
   const float* mse_c;   // [B][C] compact per-cell mse (k_cellgraph output)
   uint32_t* cand_grow;  // [B][pcap] grow index of each candidate segment
@@ -66,6 +94,7 @@ struct Regions2Extra {
   int img_bytes;            // multiple of 16
   const uint32_t* bin_off;  // sorted tiers: [B][nb + 1] offsets of each bin's list inside rb.order (dpx_binsort.h)
   uint32_t* g_qpos;         // tier 0: [B][C] queue position of each cell
+  int sort_pad;             // tier 2: power of two >= C, slots of the in-LDS seed-list sort
   int csr_chunk;            // merge phase: rows with more adjacency entries than this (<= 64) use the bit-row walk
   int32_t* labels_out[8];   // non-null: the tail also expands the cell labels to the pixel label map (fused K6);
   int frames_per_out;       // frame f writes to labels_out[f / frames_per_out] (grouped submissions have one buffer each)
@@ -109,28 +138,28 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
   extern __shared__ __align__(16) unsigned char smem[];
+  const R2Layout lay = r2_layout(TIER, C, nb);
   int* hdr = reinterpret_cast<int*>(smem);  // 48 ints: 0 planar count, 1 tail, 2 ngrow, 3 ncand, 5 nnz bins, 16.. wave counts
-  int* hist = hdr + 48;
-  int* cursor = hist + nb;           // nb: fill cursor, then END of bin b's (compacted) cell list
-  float* stage = reinterpret_cast<float*>(cursor + nb);  // kRW waves x 32 entries x 9 floats (2304 floats for 8 waves)
-  float* mse_l = stage + kStageFloats;                     // FULL: C floats
-  unsigned char* lp = reinterpret_cast<unsigned char*>(mse_l + (FULL ? C : 0));
+  int* hist = reinterpret_cast<int*>(smem + lay.hist);
+  int* cursor = reinterpret_cast<int*>(smem + lay.cursor);  // END of bin b's cell list
+  idx_t* bin_start = reinterpret_cast<idx_t*>(smem + lay.bin_start);  // nb + 1 (+1 pad): head of bin b's cell list
+  uint16_t* nzlist = reinterpret_cast<uint16_t*>(smem + lay.nzlist);   // non-empty bins, ascending
+  uint8_t* flags = smem + lay.flags;
   idx_t *qpos, *queue, *order;
   if constexpr (GST) {
     qpos = rx.g_qpos + static_cast<size_t>(frame) * C;
     queue = rb.g_queue + static_cast<size_t>(frame) * C;
     order = rb.order + static_cast<size_t>(frame) * C;
   } else {
-    qpos = reinterpret_cast<idx_t*>(lp);
-    queue = qpos + C;
-    order = queue + C;
-    lp = reinterpret_cast<unsigned char*>(order + C);
+    qpos = reinterpret_cast<idx_t*>(smem + lay.qpos);
+    queue = reinterpret_cast<idx_t*>(smem + lay.queue);
+    order = reinterpret_cast<idx_t*>(smem + lay.order);
   }
-  uint16_t* binof = reinterpret_cast<uint16_t*>(lp);  // FULL: C (bin + 1)
-  idx_t* bin_start = reinterpret_cast<idx_t*>(binof + (FULL ? C : 0));  // nb + 1 (+1 pad): begin of bin b's cell list
-  uint8_t* flags = reinterpret_cast<uint8_t*>(bin_start + nb + 2);
-  // (the list of non-empty bins lives in the first nb uint16 of `stage` during P1; stage is not used before P2)
-  uint16_t* nzlist = reinterpret_cast<uint16_t*>(stage);
+  uint16_t* binof = reinterpret_cast<uint16_t*>(smem + lay.binof);  // FULL: C (bin + 1)
+  // phase-local, behind the image: float staging of the tail phases (P2.., also the merge phase's bit matrix) and,
+  // in the tier-2 preparation, the 64-bit sort keys
+  float* stage = reinterpret_cast<float*>(smem + lay.image_end);
+  unsigned long long* skeys = reinterpret_cast<unsigned long long*>(smem + lay.image_end);
 
   const dpx_cell* cells = rb.cells + static_cast<size_t>(frame) * C;
   const uint32_t* meta = rb.meta + static_cast<size_t>(frame) * C;
@@ -157,8 +186,11 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
   __syncthreads();
   {
     int planar_cnt = 0;
-    for (int c = tid; c < C; c += kRT) {
+    for (int c0 = 0; c0 < C; c0 += kRT) {  // (uniform trip count: the key compaction below uses wave ballots)
+      const int c = c0 + tid < C ? c0 + tid : C - 1;
+      const bool live = c0 + tid < C;
       uint32_t fl, bin1;
+      unsigned long long fkey = ~0ull;
       if (FULL) {
         // fused K3 (k_cellgraph): planar bit, histogram bin and the four IN-edges of the growSeed predicate
         // (plane_extractor.cpp:377-383) straight from the plane-fit records; no meta/mse round trip through HBM
@@ -188,19 +220,34 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
           }
         }
         binof[c] = static_cast<uint16_t>(bin1);
-        mse_l[c] = q3.y;
+        // sort key of the seed lists (dpx_binsort.h): bin, then MSE, then cell id; cells without a bin sort last
+        const int kb = static_cast<int>(bin1) - 1;
+        fkey = (fl && kb >= 0 && kb < nb)
+                   ? (static_cast<unsigned long long>(kb) << kKeyBinShift) |
+                         (static_cast<unsigned long long>(sort_mse_key(q3.y)) << kKeyCellBits) | static_cast<unsigned long long>(c)
+                   : ~0ull;
       } else {
         const uint32_t m = meta[c];
         // LDS flag byte: bit 0 unassigned, bits 2..5 IN-edges (neighbour U/D/L/R of this cell may activate it)
         fl = (m & F_UNASSIGNED) | (((m >> 8) & 0xFu) << 2);
         bin1 = m >> META_BIN_SHIFT;
       }
-      flags[c] = static_cast<uint8_t>(fl);
-      qpos[c] = static_cast<idx_t>(kNoPos);
-      if (fl & F_UNASSIGNED) {
-        ++planar_cnt;
-        const int b = static_cast<int>(bin1) - 1;
-        if (FULL && b >= 0 && b < nb) atomicAdd(&hist[b], 1);
+      if (live) {
+        flags[c] = static_cast<uint8_t>(fl);
+        qpos[c] = static_cast<idx_t>(kNoPos);
+        if (fl & F_UNASSIGNED) {
+          ++planar_cnt;
+          const int b = static_cast<int>(bin1) - 1;
+          if (FULL && b >= 0 && b < nb) atomicAdd(&hist[b], 1);
+        }
+      }
+      if constexpr (FULL) {  // compact the valid keys (any order: they are sorted next), one LDS atomic per wave
+        const bool has = live && fkey != ~0ull;
+        const unsigned long long hm = __ballot(has);
+        int base = 0;
+        if (lane == 0 && hm) base = atomicAdd(&hdr[6], __popcll(hm));
+        base = __shfl(base, 0);
+        if (has) skeys[base + __popcll(hm & lt_mask)] = fkey;
       }
     }
     if constexpr (!FULL) {  // bin counts and list bounds come from the sorted seed lists
@@ -229,7 +276,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
       const int incl = wave_incl_scan(v, lane);
       if (FULL && b < nb) {
         bin_start[b] = static_cast<idx_t>(carry + incl - v);
-        cursor[b] = carry + incl - v;
+        cursor[b] = carry + incl;
       }
       carry += __shfl(incl, 63);
       // compact list of non-empty bins, ascending
@@ -242,13 +289,27 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
   }
   __syncthreads();
   if constexpr (FULL) {
-    for (int c = tid; c < C; c += kRT) {
-      const uint32_t f = flags[c];
-      if (f & F_UNASSIGNED) {
-        const int b = static_cast<int>(binof[c]) - 1;
-        if (b >= 0 && b < nb) order[atomicAdd(&cursor[b], 1)] = static_cast<uint16_t>(c);
+    // seed lists: bitonic sort of the keys in LDS (all threads), then the cell ids in sorted order.  Sorted by bin
+    // first, the list of bin b occupies exactly [bin_start[b], cursor[b]).
+    const int nkeys = hdr[6];
+    int np2 = 2;
+    while (np2 < nkeys) np2 <<= 1;  // <= rx.sort_pad
+    for (int i = nkeys + tid; i < np2; i += kRT) skeys[i] = ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+      for (int j = k >> 1; j >= 1; j >>= 1) {
+        for (int pi = tid; pi < (np2 >> 1); pi += kRT) {
+          const int lo = ((pi & ~(j - 1)) << 1) | (pi & (j - 1));
+          const int hi = lo | j;
+          const unsigned long long a = skeys[lo], b = skeys[hi];
+          if ((a > b) == ((lo & k) == 0)) {
+            skeys[lo] = b;
+            skeys[hi] = a;
+          }
+        }
+        __syncthreads();
       }
-    }
+    for (int i = tid; i < nkeys; i += kRT) order[i] = static_cast<idx_t>(skeys[i] & ((1u << kKeyCellBits) - 1u));
     __syncthreads();
   }
   }  // PHASE <= 1
@@ -260,7 +321,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
   t_p0 = DPX_STAMP();
 
   // ---------------- P1: seeds + region growing, wave 0 only ---------------------------------------------
-  // cursor[b] now holds the END of bin b's (compacted) cell list; bin_start[b] its begin.
+  // cursor[b] holds the END of bin b's sorted cell list; bin_start[b] the position of its first possibly live entry.
   if ((PHASE == 0 || PHASE == 2) && wid == 0) {
     int remaining = planar_total;
     int tail = 0, ngrow = 0, ncand = 0;
@@ -305,40 +366,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
       if (static_cast<unsigned long long>(bv) < static_cast<unsigned long long>(static_cast<long long>(prm.min_cand))) break;
       const unsigned long long tb = DPX_STAMP();
       uint32_t seed = 0xFFFFFFFFu;
-      if constexpr (FULL) {
-        // min-MSE candidate, lowest cell id among equals; the scan compacts the bin's list (drops grown cells) in place
-        const int s = bin_start[bb], e = cursor[bb];
-        uint32_t bm = 0xFFFFFFFFu, bi = 0xFFFFFFFFu, anyc = 0xFFFFFFFFu;
-        int outp = s;
-        for (int base = s; base < e; base += 64) {
-          const int i = base + lane;
-          uint32_t c = 0;
-          bool alive = false;
-          if (i < e) {
-            c = order[i];
-            alive = (flags[c] & F_UNASSIGNED) != 0;
-          }
-          const unsigned long long am = __ballot(alive);
-          if (alive) {
-            order[outp + __popcll(am & lt_mask)] = static_cast<uint16_t>(c);
-            anyc = c < anyc ? c : anyc;
-            float m = FULL ? mse_l[c] : mse_c[c];
-            if (static_cast<double>(m) < 2147483647.0) {
-              m = m + 0.0f;  // -0 -> +0: the reference's float compare treats them as equal
-              const uint32_t om = ordered_f32(m);
-              if (om < bm || (om == bm && c < bi)) {
-                bm = om;
-                bi = c;
-              }
-            }
-          }
-          outp += __popcll(am);
-        }
-        if (lane == 0) cursor[bb] = outp;
-        const uint32_t gm = wave_min_u32(bm);
-        bi = wave_min_u32(bm == gm ? bi : 0xFFFFFFFFu);
-        seed = (gm != 0xFFFFFFFFu) ? bi : wave_min_u32(anyc);
-      } else {
+      {
         // the bin's list is sorted by (mse, cell id): the seed is its first live entry.  bin_start[bb] only moves
         // forward (a grown cell never comes back), so every list entry is skipped at most once per frame.
         //
