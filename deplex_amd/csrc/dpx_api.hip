@@ -366,15 +366,19 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   if (prof) DPX_HIP(hipEventRecord(ev[5], s));
   if (!skip_l && !fuse_labels) {
     const bool labels_v1 = h->opt_labels_v1;
-    dpx::Params ps = prm;
-    ps.batch = per_sub;
-    for (int j = 0; j < nsub; ++j) {
-      const int32_t* cl = h->d_cell_labels + static_cast<size_t>(j) * per_sub * prm.C;
-      if ((prm.W & 3) == 0 && prm.nv + 1 <= 65535 && !labels_v1) {
-        const int extra = prm.H > prm.nv * prm.P ? 1 : 0;
-        if (prm.nv + extra > 0)
-          hipLaunchKernelGGL(dpx::k_labels_rows, dim3(per_sub, prm.nv + extra), dim3(256), 0, s, ps, cl, subs[j].d_labels);
-      } else {
+    if ((prm.W & 3) == 0 && prm.nv + 1 <= 65535 && !labels_v1) {
+      // one launch for the whole group: block (frame, cell row) finds its output buffer through `outs`
+      dpx::LabelOuts outs{};
+      for (int j = 0; j < 8; ++j) outs.out[j] = j < nsub ? subs[j].d_labels : nullptr;
+      outs.per_out = per_sub;
+      const int extra = prm.H > prm.nv * prm.P ? 1 : 0;
+      if (prm.nv + extra > 0)
+        hipLaunchKernelGGL(dpx::k_labels_rows, dim3(batch, prm.nv + extra), dim3(256), 0, s, prm, h->d_cell_labels, outs);
+    } else {
+      dpx::Params ps = prm;
+      ps.batch = per_sub;
+      for (int j = 0; j < nsub; ++j) {
+        const int32_t* cl = h->d_cell_labels + static_cast<size_t>(j) * per_sub * prm.C;
         const long long per_frame = static_cast<long long>(prm.H) * ((prm.W + 3) / 4);
         const long long tot = per_frame * per_sub;
         if (tot > 0)
@@ -619,7 +623,7 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
   }
   const size_t C = static_cast<size_t>(p.C);
   const size_t lds_state = hist_bytes + 6 * C + 16;
-  h->opt_nofuse = std::getenv("DPX_NO_FUSED_LABELS") != nullptr;
+  h->opt_nofuse = std::getenv("DPX_FUSED_LABELS") == nullptr;  // fusing the label expansion into the region tail measured 3-5 % slower
   h->opt_labels_v1 = std::getenv("DPX_LABELS_V1") != nullptr;
   h->opt_cloud_nolds = std::getenv("DPX_CLOUD_NOLDS") != nullptr;
   if (const char* e = std::getenv("DPX_CSR_CHUNK")) {  // test hook: force the wide-row walk of the merge phase
@@ -639,33 +643,31 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
     const char* lean = std::getenv("DPX_REGIONS_LEAN");
     const char* gst = std::getenv("DPX_REGIONS_GSTATE");
     const bool want_lean = lean && lean[0] == '1', want_gst = gst && gst[0] == '1';
-    const size_t stage_bytes = static_cast<size_t>(dpx::kStageFloats) * 4;
     size_t pad2 = 1;
     while (pad2 < C) pad2 <<= 1;
     h->regions_tier = -1;
     if (!(v1 && v1[0] == '1') && !(force && force[0] == '1') && nb < 4600) {
       const int Ci = static_cast<int>(C), nbi = static_cast<int>(nb);
-      const size_t img2 = dpx::r2_layout(2, Ci, nbi).image_end, img1 = dpx::r2_layout(1, Ci, nbi).image_end,
-                   img0 = dpx::r2_layout(0, Ci, nbi).image_end;
-      if (C < 65000 && img2 + std::max(stage_bytes, 8 * pad2) <= kLdsLimit && !want_lean && !want_gst) {
+      const dpx::R2Layout l2 = dpx::r2_layout(2, Ci, nbi), l1 = dpx::r2_layout(1, Ci, nbi), l0 = dpx::r2_layout(0, Ci, nbi);
+      if (C < 65000 && std::max<size_t>(l2.tail_end, l2.image_end + 8 * pad2) <= kLdsLimit && !want_lean && !want_gst) {
         h->regions_tier = 2;
         h->sort_pad = static_cast<int>(pad2);
-        h->lds2_img = img2;
-        h->lds2_p1 = img2 + 8 * pad2;
-        h->lds2_p2 = img2;
-        h->lds2_p3 = img2 + stage_bytes;
-        h->lds2_bytes = img2 + std::max(stage_bytes, 8 * pad2);
-      } else if (C < 65000 && img1 + stage_bytes <= kLdsLimit && !want_gst) {
+        h->lds2_img = l2.image_end;
+        h->lds2_p1 = l2.image_end + 8 * pad2;
+        h->lds2_p2 = l2.image_end;
+        h->lds2_p3 = l2.tail_end;
+        h->lds2_bytes = std::max<size_t>(l2.tail_end, l2.image_end + 8 * pad2);
+      } else if (C < 65000 && l1.tail_end <= kLdsLimit && !want_gst) {
         h->regions_tier = 1;
-        h->lds2_img = img1;
-        h->lds2_p1 = img1;
-        h->lds2_p2 = img1;
-        h->lds2_p3 = img1 + stage_bytes;
-        h->lds2_bytes = img1 + stage_bytes;
-      } else if (C < (size_t(1) << dpx::kKeyCellBits) && img0 + stage_bytes <= kLdsLimit) {
+        h->lds2_img = l1.image_end;
+        h->lds2_p1 = l1.image_end;
+        h->lds2_p2 = l1.image_end;
+        h->lds2_p3 = l1.tail_end;
+        h->lds2_bytes = l1.tail_end;
+      } else if (C < (size_t(1) << dpx::kKeyCellBits) && l0.tail_end <= kLdsLimit) {
         h->regions_tier = 0;
-        h->lds2_img = img0;
-        h->lds2_bytes = img0 + stage_bytes;
+        h->lds2_img = l0.image_end;
+        h->lds2_bytes = l0.tail_end;
       }
     }
     if (h->regions_tier == 1 || h->regions_tier == 0) {

@@ -457,16 +457,22 @@ __global__ __launch_bounds__(256) void k_labels(Params prm, const int32_t* __res
 // same label pattern, so a thread builds its 4-pixel int4 once (labels of the cell row staged in LDS) and stores it to
 // all P rows: ~1 store per 16 output bytes and almost no arithmetic.  blockIdx.y == nv handles the image rows below
 // the last full cell row (H % P != 0), which are 0.
-__global__ __launch_bounds__(256) void k_labels_rows(Params prm, const int32_t* __restrict__ cell_labels, int32_t* __restrict__ labels) {
+// Frames of a grouped submission go to up to eight output buffers (`per_out` frames each).
+struct LabelOuts {
+  int32_t* out[8];
+  int per_out;
+};
+__global__ __launch_bounds__(256) void k_labels_rows(Params prm, const int32_t* __restrict__ cell_labels, LabelOuts outs) {
   __shared__ int32_t cl[1024];
   const int frame = blockIdx.x;
+  const int sub = frame / outs.per_out;
+  int32_t* __restrict__ dst = outs.out[sub] + static_cast<long long>(frame - sub * outs.per_out) * prm.N;
   const int cr = blockIdx.y;
   const int W4 = prm.W >> 2;
   const bool tail = cr >= prm.nv;  // rows outside the cell grid
   const int row_begin = tail ? prm.nv * prm.P : cr * prm.P;
   const int row_end = tail ? prm.H : row_begin + prm.P;
   const int32_t* src = cell_labels + static_cast<long long>(frame) * prm.C + static_cast<long long>(cr) * prm.nh;
-  int32_t* dst = labels + static_cast<long long>(frame) * prm.N;
   for (int c0 = 0; c0 < prm.nh || c0 == 0; c0 += 1024) {  // cell rows wider than 1024 cells are processed in slabs
     __syncthreads();
     for (int c = threadIdx.x; c < 1024; c += 256) cl[c] = (!tail && c0 + c < prm.nh) ? src[c0 + c] : 0;

@@ -60,10 +60,12 @@ constexpr int kStage = 32;         // entries of the per-wave staging buffer of 
 constexpr int kStageFloats = (kRW * kStage * 9 > 2304) ? kRW * kStage * 9 : 2304;  // the merge phase needs 2304 words
 
 // LDS image of a frame's region-growing state (byte offsets), shared by the device code and the host's size
-// computation.  Everything up to image_end is handed from launch to launch in split mode; the float staging buffer
-// of the tail phases and the sort keys of the tier-2 preparation live behind it and are phase-local.
+// computation.  Everything up to image_end is handed from launch to launch in split mode.  The float staging buffer of
+// the tail phases (accumulation, merge bit matrix) reuses the block hist..binof, which is dead by then, when that
+// block is large enough, and lies behind the image otherwise; the sort keys of the tier-2 preparation always lie
+// behind the image.
 struct R2Layout {
-  uint32_t hist, cursor, bin_start, nzlist, flags, qpos, queue, order, binof, image_end;
+  uint32_t hist, cursor, bin_start, nzlist, flags, binof, qpos, queue, order, image_end, stage, tail_end;
 };
 __host__ __device__ inline R2Layout r2_layout(int tier, int C, int nb) {
   R2Layout L{};
@@ -76,13 +78,23 @@ __host__ __device__ inline R2Layout r2_layout(int tier, int C, int nb) {
   o = (o + 3u) & ~3u;
   L.flags = o; o += static_cast<uint32_t>(C);
   o = (o + 3u) & ~3u;
+  if (tier == 2) { L.binof = o; o += 2u * C; }
+  o = (o + 3u) & ~3u;
+  const uint32_t dead_end = o;  // hist..here is not read after the grow phase
   if (tier >= 1) {
     L.qpos = o; o += 2u * C;
     L.queue = o; o += 2u * C;
     L.order = o; o += 2u * C;
   }
-  if (tier == 2) { L.binof = o; o += 2u * C; }
   L.image_end = (o + 15u) & ~15u;
+  const uint32_t stage_bytes = static_cast<uint32_t>(kStageFloats) * 4u;
+  if (dead_end - L.hist >= stage_bytes) {
+    L.stage = L.hist;
+    L.tail_end = L.image_end;
+  } else {
+    L.stage = L.image_end;
+    L.tail_end = L.image_end + stage_bytes;
+  }
   return L;
 }
 
@@ -156,9 +168,9 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
     order = reinterpret_cast<idx_t*>(smem + lay.order);
   }
   uint16_t* binof = reinterpret_cast<uint16_t*>(smem + lay.binof);  // FULL: C (bin + 1)
-  // phase-local, behind the image: float staging of the tail phases (P2.., also the merge phase's bit matrix) and,
-  // in the tier-2 preparation, the 64-bit sort keys
-  float* stage = reinterpret_cast<float*>(smem + lay.image_end);
+  // phase-local: float staging of the tail phases (P2.., also the merge phase's bit matrix; see r2_layout) and, in
+  // the tier-2 preparation, the 64-bit sort keys behind the image
+  float* stage = reinterpret_cast<float*>(smem + lay.stage);
   unsigned long long* skeys = reinterpret_cast<unsigned long long*>(smem + lay.image_end);
 
   const dpx_cell* cells = rb.cells + static_cast<size_t>(frame) * C;
@@ -296,8 +308,10 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
     while (np2 < nkeys) np2 <<= 1;  // <= rx.sort_pad
     for (int i = nkeys + tid; i < np2; i += kRT) skeys[i] = ~0ull;
     __syncthreads();
-    for (int k = 2; k <= np2; k <<= 1)
-      for (int j = k >> 1; j >= 1; j >>= 1) {
+    // Strides >= 64 are workgroup-wide compare-exchange passes; the strides below 64 of a stage stay inside aligned
+    // 128-key chunks, so a wave finishes them chunk by chunk on its own (one pair per lane, no workgroup barrier).
+    for (int k = 2; k <= np2; k <<= 1) {
+      for (int j = k >> 1; j >= 64; j >>= 1) {
         for (int pi = tid; pi < (np2 >> 1); pi += kRT) {
           const int lo = ((pi & ~(j - 1)) << 1) | (pi & (j - 1));
           const int hi = lo | j;
@@ -309,6 +323,23 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
         }
         __syncthreads();
       }
+      const int j0 = (k >> 1) < 32 ? (k >> 1) : 32;
+      for (int cb = wid * 128; cb < np2; cb += kRW * 128) {
+        for (int j = j0; j >= 1; j >>= 1) {
+          const int lo = cb + (((lane & ~(j - 1)) << 1) | (lane & (j - 1)));
+          const int hi = lo | j;
+          if (hi < np2) {  // (np2 < 128 only for tiny frames)
+            const unsigned long long a = skeys[lo], b = skeys[hi];
+            if ((a > b) == ((lo & k) == 0)) {
+              skeys[lo] = b;
+              skeys[hi] = a;
+            }
+          }
+          wave_sync();
+        }
+      }
+      __syncthreads();
+    }
     for (int i = tid; i < nkeys; i += kRT) order[i] = static_cast<idx_t>(skeys[i] & ((1u << kKeyCellBits) - 1u));
     __syncthreads();
   }
@@ -453,6 +484,8 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
         const int wU = v - nh > 0 ? v - nh : 0, wD = v + nh < C ? v + nh : C - 1;
         const int wL = v - 1 > 0 ? v - 1 : 0, wR = v + 1 < C ? v + 1 : C - 1;
         const uint32_t qU = qpos[wU], qD = qpos[wD], qL = qpos[wL], qR = qpos[wR];
+        // v's bin, needed only if v is activated, is fetched with the reads above instead of after the decision
+        const int bin_v = (FULL ? static_cast<int>(binof[v]) : static_cast<int>(meta[v] >> META_BIN_SHIFT)) - 1;
         const uint32_t uh = static_cast<uint32_t>(head), us = static_cast<uint32_t>(slot);
         // bit k set: v's neighbour k sits EARLIER in this FIFO batch (queue position in [head, head + slot))
         const uint32_t earlier = (((qU - uh) < us) ? 1u : 0u) | (((qD - uh) < us) ? 2u : 0u) |
@@ -469,12 +502,18 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
           queue[pos] = static_cast<idx_t>(v);
           qpos[v] = static_cast<idx_t>(pos);
           flags[v] = static_cast<uint8_t>(fv & ~F_UNASSIGNED);
-          const int b = (FULL ? static_cast<int>(binof[v]) : static_cast<int>(meta[v] >> META_BIN_SHIFT)) - 1;
-          if (b >= 0 && b < nb) atomicSub(&hist[b], 1);  // hist.removePoint at activation time
+          if (bin_v >= 0 && bin_v < nb) atomicSub(&hist[bin_v], 1);  // hist.removePoint at activation time
         }
         tail += __popcll(mask);
         head += nslots;
-        wave_sync();
+        if constexpr (GST) {
+          wave_sync();  // queue / queue positions in global memory: the next step's loads must see these stores
+        } else {
+          // LDS executes a wave's operations in order, so the next step's reads see this step's writes without
+          // waiting for them to retire; only the compiler has to keep the order
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
+        }
         if (DBG) ++n_steps;
       }
       const unsigned long long td = DPX_STAMP();
