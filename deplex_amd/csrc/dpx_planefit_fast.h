@@ -101,7 +101,9 @@ struct CellAcc {
   // One pixel.  KM = k & 7 and the position flags are compile-time; the row index may be a runtime value.
   template <int J, int KM, bool TAIL, int TAILIDX, bool FIRST, bool LAST, bool HROW>
   __device__ __forceinline__ void pixel(uint32_t zi, float cx_j, float cy_i, const Params& prm, float rx, float ry) {
-    const float z = static_cast<float>(zi);
+    float z = static_cast<float>(zi);
+    // hide that z came from an integer: otherwise z * z is rewritten as convert(zi * zi) — two instructions for one
+    asm volatile("" : "+v"(z));
     const float x = div_const<FASTDIV>(cx_j * z, prm.fx, rx);
     const float y = div_const<FASTDIV>(cy_i * z, prm.fy, ry);
     valid_pts += zi != 0u;
