@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DPX_BENCH_STREAMS", 16)))
-    ap.add_argument("--group", type=int, default=int(os.environ.get("DPX_BENCH_GROUP", 4)), help="submissions per region-growing launch")
+    ap.add_argument("--group", type=int, default=int(os.environ.get("DPX_BENCH_GROUP", 8)), help="submissions per region-growing launch")
     ap.add_argument("--prof-every", type=int, default=8, help="record per-kernel HIP events on every n-th slot")
     ap.add_argument("--roofline-iters", type=int, default=50)
     ap.add_argument("--no-cloud-roofline", action="store_true")
@@ -229,7 +229,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl_desc, "patch_size": 10, "batch_per_gpu": B, "groups_in_flight": S, "batches_per_region_launch": G,
-                       "streams": f"{S} (one per batch in flight), GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}",
+                       "streams": f"{S} (one per group in flight), GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}",
                        "arithmetic": "f32 moments (reference order), f64 3x3 eigen, int32 labels",
                        "parallelism": f"frame-shard x{world}, no collectives"},
             "parity": parity,
@@ -240,7 +240,7 @@ def main():
                          "bytes_per_launch": pf_bytes, "avg_launch_ms": round(pf_ms, 4),
                          "measured": f"{args.roofline_iters} launches back to back on one stream after the timed region, HIP events on that stream",
                          "in_pipeline": {"avg_launch_ms": round(kms["planefit"], 4), "achieved": round(in_pipe, 1),
-                                         "note": f"HIP events around the launches of the timed steps with {S} batches in flight (includes queueing behind / sharing with the other batches' kernels)"}},
+                                         "note": f"HIP events around the launches of the timed steps with {S} groups of {G} batches in flight (includes queueing behind / sharing with the other batches' kernels)"}},
         }
         if cloud_ms:
             cb = exs[0].planefit_bytes(1, B)
