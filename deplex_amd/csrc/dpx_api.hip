@@ -934,6 +934,7 @@ int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_
 struct dpx_pipeline_s {
   std::vector<dpx_handle> slots;
   std::vector<std::vector<SubBatch>> pending;  // per slot: submissions whose plane fit ran, region stage not yet
+  std::vector<char> pending_depth;             // per slot: input form of the pending submissions (1 depth, 0 cloud)
   int group = 1, batch = 0;
   long long submitted = 0;
   int device = 0;
@@ -943,7 +944,7 @@ namespace {
 int pipeline_flush(dpx_pipeline p, size_t k) {
   if (p->pending[k].empty()) return DPX_OK;
   dpx_handle h = p->slots[k];
-  const int rc = stage_rest(h, p->pending[k].data(), static_cast<int>(p->pending[k].size()), p->batch, true, h->stream);
+  const int rc = stage_rest(h, p->pending[k].data(), static_cast<int>(p->pending[k].size()), p->batch, p->pending_depth[k] != 0, h->stream);
   p->pending[k].clear();
   return rc;
 }
@@ -971,6 +972,7 @@ int dpx_pipeline_create(const dpx_config* cfg, int32_t image_height, int32_t ima
     p->slots.push_back(h);
   }
   p->pending.resize(p->slots.size());
+  p->pending_depth.assign(p->slots.size(), 1);
   *out = p;
   return DPX_OK;
 }
@@ -983,19 +985,39 @@ void dpx_pipeline_destroy(dpx_pipeline p) {
   delete p;
 }
 
-int dpx_pipeline_submit_depth(dpx_pipeline p, const void* d_depth, int32_t batch, float fx, float fy, float cx, float cy,
-                              void* d_labels) {
-  if (!p || !d_depth || !d_labels) return fail(DPX_ERR_ARG, "bad argument");
+namespace {
+int pipeline_submit(dpx_pipeline p, const void* d_in, bool depth, int32_t batch, float fx, float fy, float cx, float cy, void* d_labels) {
+  if (!p || !d_in || !d_labels) return fail(DPX_ERR_ARG, "bad argument");
   if (batch != p->batch) return fail(DPX_ERR_ARG, "pipeline submissions must have the batch size given at creation");
-  const long long n = p->submitted++;
-  const size_t k = static_cast<size_t>((n / p->group) % static_cast<long long>(p->slots.size()));
+  long long n = p->submitted;
+  size_t k = static_cast<size_t>((n / p->group) % static_cast<long long>(p->slots.size()));
+  if (!p->pending[k].empty() && (p->pending_depth[k] != 0) != depth) {
+    // a group holds one input form (the refinement re-reads the input): close the open group and start a new one
+    const int rcf = pipeline_flush(p, k);
+    if (rcf) return rcf;
+    p->submitted = ((p->submitted + p->group - 1) / p->group) * p->group;
+    n = p->submitted;
+    k = static_cast<size_t>((n / p->group) % static_cast<long long>(p->slots.size()));
+  }
+  ++p->submitted;
   const int j = static_cast<int>(n % p->group);
   dpx_handle h = p->slots[k];
-  int rc = stage_fit(h, d_depth, true, batch, fx, fy, cx, cy, j * p->batch, h->stream);
+  int rc = stage_fit(h, d_in, depth, batch, fx, fy, cx, cy, j * p->batch, h->stream);
   if (rc) return rc;
-  p->pending[k].push_back(SubBatch{d_depth, static_cast<int32_t*>(d_labels)});
+  p->pending_depth[k] = depth ? 1 : 0;
+  p->pending[k].push_back(SubBatch{d_in, static_cast<int32_t*>(d_labels)});
   if (j == p->group - 1) rc = pipeline_flush(p, k);
   return rc;
+}
+}  // namespace
+
+int dpx_pipeline_submit_depth(dpx_pipeline p, const void* d_depth, int32_t batch, float fx, float fy, float cx, float cy,
+                              void* d_labels) {
+  return pipeline_submit(p, d_depth, true, batch, fx, fy, cx, cy, d_labels);
+}
+
+int dpx_pipeline_submit_pcd(dpx_pipeline p, const void* d_xyz, int32_t batch, void* d_labels) {
+  return pipeline_submit(p, d_xyz, false, batch, 1.f, 1.f, 0.f, 0.f, d_labels);
 }
 
 int dpx_pipeline_sync(dpx_pipeline p) {

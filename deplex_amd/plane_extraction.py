@@ -234,6 +234,10 @@ class Pipeline:
     def submit_depth(self, d_depth_ptr: int, batch: int, fx, fy, cx, cy, d_labels_ptr: int) -> None:
         _capi.check(_capi.lib().dpx_pipeline_submit_depth(self._p, d_depth_ptr, batch, fx, fy, cx, cy, d_labels_ptr))
 
+    def submit_pcd(self, d_xyz_ptr: int, batch: int, d_labels_ptr: int) -> None:
+        """Organised clouds (float32 [batch][H*W][3]) in device memory, the reference API's own input form."""
+        _capi.check(_capi.lib().dpx_pipeline_submit_pcd(self._p, d_xyz_ptr, batch, d_labels_ptr))
+
     def sync(self) -> None:
         _capi.check(_capi.lib().dpx_pipeline_sync(self._p))
 

@@ -145,6 +145,9 @@ int dpx_pipeline_create(const dpx_config* cfg, int32_t image_height, int32_t ima
 void dpx_pipeline_destroy(dpx_pipeline p);
 int dpx_pipeline_submit_depth(dpx_pipeline p, const void* d_depth, int32_t batch, float fx, float fy, float cx, float cy,
                               void* d_labels);
+/* The same for organised clouds (float32 [batch][H*W][3], the input of PlaneExtractor::process, plane_extractor.h:48).
+ * A group holds one input form; switching forms closes the open group first. */
+int dpx_pipeline_submit_pcd(dpx_pipeline p, const void* d_xyz, int32_t batch, void* d_labels);
 int dpx_pipeline_sync(dpx_pipeline p);
 dpx_handle dpx_pipeline_slot(dpx_pipeline p, int32_t slot);
 

@@ -412,6 +412,19 @@ def test_multistream_pipeline(D, oracle):
             assert np.array_equal(d_out[i].cpu().numpy(), refs[i]), f"group {group} second round batch {i}"
         with pytest.raises(RuntimeError):
             pipe.submit_depth(d_in[0].data_ptr(), B - 1, *intr, d_out[0].data_ptr())
+        # organised clouds through the same pipeline, interleaved with depth submissions (a group holds one form)
+        clouds = [torch.from_numpy(np.stack([oracle.backproject(f, *[np.float32(v) for v in intr]) for f in batches[i]])).to(dev)
+                  for i in range(3)]
+        for o in d_out[:5]:
+            o.fill_(-1)
+        pipe.submit_pcd(clouds[0].data_ptr(), B, d_out[0].data_ptr())
+        pipe.submit_depth(d_in[3].data_ptr(), B, *intr, d_out[3].data_ptr())
+        pipe.submit_pcd(clouds[1].data_ptr(), B, d_out[1].data_ptr())
+        pipe.submit_pcd(clouds[2].data_ptr(), B, d_out[2].data_ptr())
+        pipe.submit_depth(d_in[4].data_ptr(), B, *intr, d_out[4].data_ptr())
+        pipe.sync()
+        for i in range(5):
+            assert np.array_equal(d_out[i].cpu().numpy(), refs[i]), f"group {group} mixed-form batch {i}"
         del pipe
 
 
