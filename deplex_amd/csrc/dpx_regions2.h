@@ -353,7 +353,12 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
 
   // ---------------- P1: seeds + region growing, wave 0 only ---------------------------------------------
   // cursor[b] holds the END of bin b's sorted cell list; bin_start[b] the position of its first possibly live entry.
-  if ((PHASE == 0 || PHASE == 2) && wid == 0) {
+  if ((PHASE == 0 || PHASE == 2) && (GST || wid == 0)) {
+    // Tier 0 keeps all waves in this loop: wave 0 runs the grows exactly like the other tiers, the rest wait at the
+    // per-grow barrier and join when a BFS queue gets wide (>= kWideSlots pending cells): then every wave takes 16
+    // consecutive queue slots of a batch, appends in (wave, lane) order through per-wave counts, and the FIFO order
+    // stays the reference's.  All control decisions are read from LDS after a barrier, so they are workgroup-uniform.
+    constexpr int kWideSlots = 64;
     int remaining = planar_total;
     int tail = 0, ngrow = 0, ncand = 0;
     const int nnz = hdr[5];
@@ -368,154 +373,12 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
     const int delta = dir == 0 ? -nh : (dir == 1 ? nh : (dir == 2 ? -1 : 1));
     const uint32_t opp = static_cast<uint32_t>(dir ^ 1);
     const uint32_t notme = ~(1u << opp) & 0xFu;
-    for (int guard = 0; remaining > 0 && guard <= C; ++guard) {
-      const unsigned long long ta = DPX_STAMP();
-      // most frequent bin, lowest index among maxima: key = count << kBinBits | (kBinMask - bin)
-      constexpr int kBinBits = GST ? 13 : 16;  // tier 0: counts up to 2^19, bins < 2^13
-      constexpr uint32_t kBinMask = (1u << kBinBits) - 1u;
-      uint32_t key = 0;
-      if (reg_bins) {
-        if (mybin[0] >= 0) key = (static_cast<uint32_t>(hist[mybin[0]]) << kBinBits) | (kBinMask - static_cast<uint32_t>(mybin[0]));
-        if (reg_sets > 1) {  // uniform
-#pragma unroll
-          for (int q = 1; q < 4; ++q) {
-            const uint32_t k = mybin[q] >= 0 ? (static_cast<uint32_t>(hist[mybin[q]]) << kBinBits) | (kBinMask - static_cast<uint32_t>(mybin[q])) : 0u;
-            key = k > key ? k : key;
-          }
-        }
-      } else {
-        for (int t = lane; t < nnz; t += 64) {
-          const int b = nzlist[t];
-          const uint32_t k = (static_cast<uint32_t>(hist[b]) << kBinBits) | (kBinMask - static_cast<uint32_t>(b));
-          key = k > key ? k : key;
-        }
-      }
-      key = wave_max_u32(key);
-      const int bv = static_cast<int>(key >> kBinBits);
-      const int bb = static_cast<int>(kBinMask - (key & kBinMask));
-      if (bv <= 0) break;
-      if (static_cast<unsigned long long>(bv) < static_cast<unsigned long long>(static_cast<long long>(prm.min_cand))) break;
-      const unsigned long long tb = DPX_STAMP();
-      uint32_t seed = 0xFFFFFFFFu;
-      {
-        // the bin's list is sorted by (mse, cell id): the seed is its first live entry.  bin_start[bb] only moves
-        // forward (a grown cell never comes back), so every list entry is skipped at most once per frame.
-        //
-        // Isolated seeds: on noisy frames two thirds of all grows activate nothing but their seed (no neighbour is both
-        // unassigned and reachable from it).  The chunk scan reads the seed's four neighbour flags along with its own,
-        // and such a grow is committed right here — one queue slot, one grow — without a BFS step.  (Committing several
-        // in a row does not pay: the arg-max keeps the fullest bins level, so it changes bin after almost every grow.)
-        int s0 = static_cast<int>(bin_start[bb]);
-        const int e = cursor[bb];
-        const bool iso_ok = prm.min_cells > 1 || prm.min_cells < 0;  // a one-cell grow is never a segment candidate
-        bool committed = false;
-        while (s0 < e) {
-          const int i = s0 + lane;
-          uint32_t c = 0, f = 0;
-          bool alive = false, iso = false;
-          if (i < e) {
-            c = order[i];
-            const int cc = static_cast<int>(c);
-            const int wU = cc - nh > 0 ? cc - nh : 0, wD = cc + nh < C ? cc + nh : C - 1;
-            const int wL = cc > 0 ? cc - 1 : 0, wR = cc + 1 < C ? cc + 1 : C - 1;
-            f = flags[cc];
-            const uint32_t fU = flags[wU], fD = flags[wD], fL = flags[wL], fR = flags[wR];
-            alive = (f & F_UNASSIGNED) != 0;
-            // a neighbour that is unassigned and whose in-edge bit for this cell's side is set can be activated from
-            // here; clamped (non-existent) neighbours can only make a cell look connected, never isolated
-            const uint32_t out = ((fU & (fU >> 3)) | (fD & (fD >> 2)) | (fL & (fL >> 5)) | (fR & (fR >> 4))) & 1u;
-            iso = alive && out == 0u && iso_ok;
-          }
-          const unsigned long long am = __ballot(alive);
-          if (am) {
-            const int first = __builtin_ctzll(am);
-            seed = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c), first));
-            committed = ((__ballot(iso) >> first) & 1ull) != 0ull;
-            if (committed && lane == first) {
-              queue[tail] = static_cast<idx_t>(c);
-              qpos[c] = static_cast<idx_t>(tail);
-              flags[c] = static_cast<uint8_t>(f & ~F_UNASSIGNED);
-              grow_start[ngrow] = static_cast<uint32_t>(tail);
-              atomicSub(&hist[bb], 1);
-            }
-            s0 += first + 1;
-            break;
-          }
-          s0 += 64;
-        }
-        if (lane == 0) bin_start[bb] = static_cast<idx_t>(s0 < e ? s0 : e);
-        if (committed) {
-          ++tail;
-          ++ngrow;
-          --remaining;
-          wave_sync();
-          if (DBG) {
-            const unsigned long long tc2 = DPX_STAMP();
-            a_argmax += tb - ta; a_seed += tc2 - tb;
-          }
-          continue;
-        }
-      }
-      if (seed == 0xFFFFFFFFu) break;
-
-      const unsigned long long tc = DPX_STAMP();
-      const int gstart = tail;
-      if (lane == 0) {
-        queue[tail] = static_cast<idx_t>(seed);
-        qpos[seed] = static_cast<idx_t>(tail);
-        flags[seed] = static_cast<uint8_t>(flags[seed] & ~F_UNASSIGNED);
-        atomicSub(&hist[bb], 1);  // hist.removePoint(seed); the seed's bin is bb
-      }
-      ++tail;
-      int head = gstart;
-      wave_sync();
-      while (head < tail) {
-        // Branch-free step: lane = (slot, dir).  All LDS reads are unconditional (clamped addresses), the decision is
-        // pure bit arithmetic: a single wave issues one instruction per ~4 cycles, so instruction count is latency.
-        const int nslots = (tail - head) < 16 ? (tail - head) : 16;
-        const int qi = head + (slot < nslots ? slot : 0);
-        const int u = queue[qi];
-        const int vraw = u + delta;
-        const bool inrange = (slot < nslots) && (vraw >= 0) && (vraw < C);
-        const int v = vraw < 0 ? 0 : (vraw >= C ? C - 1 : vraw);
-        const uint32_t fv = flags[v];
-        // positions of v's four neighbours in the queue (0xFFFF = never activated); out-of-grid neighbours are
-        // clamped to a valid address and are harmless because v's in-edge bit for them is 0 (k_cellgraph)
-        const int wU = v - nh > 0 ? v - nh : 0, wD = v + nh < C ? v + nh : C - 1;
-        const int wL = v - 1 > 0 ? v - 1 : 0, wR = v + 1 < C ? v + 1 : C - 1;
-        const uint32_t qU = qpos[wU], qD = qpos[wD], qL = qpos[wL], qR = qpos[wR];
-        // v's bin, needed only if v is activated, is fetched with the reads above instead of after the decision
-        const int bin_v = (FULL ? static_cast<int>(binof[v]) : static_cast<int>(meta[v] >> META_BIN_SHIFT)) - 1;
-        const uint32_t uh = static_cast<uint32_t>(head), us = static_cast<uint32_t>(slot);
-        // bit k set: v's neighbour k sits EARLIER in this FIFO batch (queue position in [head, head + slot))
-        const uint32_t earlier = (((qU - uh) < us) ? 1u : 0u) | (((qD - uh) < us) ? 2u : 0u) |
-                                 (((qL - uh) < us) ? 4u : 0u) | (((qR - uh) < us) ? 8u : 0u);
-        const uint32_t inb = (fv >> 2) & 0xFu;  // in-edge bits of v
-        // u is v's neighbour number dir^1: v accepts u iff that in-edge is set; u loses to any OTHER in-neighbour
-        // that is earlier in the batch.  Integer logic only (no short-circuit): keeps the five LDS reads above in
-        // one batch instead of three dependent round trips.
-        const uint32_t okbits = (inrange ? 1u : 0u) & fv & (inb >> opp) & (((inb & earlier & notme) == 0u) ? 1u : 0u);
-        const bool win = okbits != 0u;
-        const unsigned long long mask = __ballot(win);
-        if (win) {
-          const int pos = tail + __popcll(mask & lt_mask);
-          queue[pos] = static_cast<idx_t>(v);
-          qpos[v] = static_cast<idx_t>(pos);
-          flags[v] = static_cast<uint8_t>(fv & ~F_UNASSIGNED);
-          if (bin_v >= 0 && bin_v < nb) atomicSub(&hist[bin_v], 1);  // hist.removePoint at activation time
-        }
-        tail += __popcll(mask);
-        head += nslots;
-        if constexpr (GST) {
-          wave_sync();  // queue / queue positions in global memory: the next step's loads must see these stores
-        } else {
-          // LDS executes a wave's operations in order, so the next step's reads see this step's writes without
-          // waiting for them to retire; only the compiler has to keep the order
-          asm volatile("" ::: "memory");
-          __builtin_amdgcn_wave_barrier();
-        }
-        if (DBG) ++n_steps;
-      }
+    int guard = 0;  // grows started (wave 0's count; the reference's loop ends by itself, this is a safety net)
+    int head = 0, gstart = 0;
+    bool in_grow = false;
+    unsigned long long ta = 0, tb = 0, tc = 0;
+    // segment bookkeeping of a finished grow (wave 0)
+    auto finish_grow = [&]() {
       const unsigned long long td = DPX_STAMP();
       const int g = tail - gstart;
       const bool is_cand = !(static_cast<unsigned long long>(g) < static_cast<unsigned long long>(static_cast<long long>(prm.min_cells))) &&
@@ -531,8 +394,251 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
         const unsigned long long te = DPX_STAMP();
         a_argmax += tb - ta; a_seed += tc - tb; a_bfs += td - tc; a_rem += te - td;
       }
+    };
+    for (int round = 0;; ++round) {
+      int st = 2;  // 2: no further grow, 0: wave 0 finished this grow's BFS (or committed it), 1: wide BFS wanted
+      if (!GST || wid == 0) {
+        // wave 0 runs grow after grow on its own and comes to the barrier below only to ask for a wide BFS or to end
+        for (;; ++guard) {
+        st = 2;
+        in_grow = false;
+        do {
+          if (!(remaining > 0 && guard <= C)) break;
+          ta = DPX_STAMP();
+          // most frequent bin, lowest index among maxima: key = count << kBinBits | (kBinMask - bin)
+          constexpr int kBinBits = GST ? 13 : 16;  // tier 0: counts up to 2^19, bins < 2^13
+          constexpr uint32_t kBinMask = (1u << kBinBits) - 1u;
+          uint32_t key = 0;
+          if (reg_bins) {
+            if (mybin[0] >= 0) key = (static_cast<uint32_t>(hist[mybin[0]]) << kBinBits) | (kBinMask - static_cast<uint32_t>(mybin[0]));
+            if (reg_sets > 1) {  // uniform
+    #pragma unroll
+              for (int q = 1; q < 4; ++q) {
+                const uint32_t k = mybin[q] >= 0 ? (static_cast<uint32_t>(hist[mybin[q]]) << kBinBits) | (kBinMask - static_cast<uint32_t>(mybin[q])) : 0u;
+                key = k > key ? k : key;
+              }
+            }
+          } else {
+            for (int t = lane; t < nnz; t += 64) {
+              const int b = nzlist[t];
+              const uint32_t k = (static_cast<uint32_t>(hist[b]) << kBinBits) | (kBinMask - static_cast<uint32_t>(b));
+              key = k > key ? k : key;
+            }
+          }
+          key = wave_max_u32(key);
+          const int bv = static_cast<int>(key >> kBinBits);
+          const int bb = static_cast<int>(kBinMask - (key & kBinMask));
+          if (bv <= 0) break;
+          if (static_cast<unsigned long long>(bv) < static_cast<unsigned long long>(static_cast<long long>(prm.min_cand))) break;
+          tb = DPX_STAMP();
+          uint32_t seed = 0xFFFFFFFFu;
+          {
+            // the bin's list is sorted by (mse, cell id): the seed is its first live entry.  bin_start[bb] only moves
+            // forward (a grown cell never comes back), so every list entry is skipped at most once per frame.
+            //
+            // Isolated seeds: on noisy frames two thirds of all grows activate nothing but their seed (no neighbour is both
+            // unassigned and reachable from it).  The chunk scan reads the seed's four neighbour flags along with its own,
+            // and such a grow is committed right here — one queue slot, one grow — without a BFS step.  (Committing several
+            // in a row does not pay: the arg-max keeps the fullest bins level, so it changes bin after almost every grow.)
+            int s0 = static_cast<int>(bin_start[bb]);
+            const int e = cursor[bb];
+            const bool iso_ok = prm.min_cells > 1 || prm.min_cells < 0;  // a one-cell grow is never a segment candidate
+            bool committed = false;
+            while (s0 < e) {
+              const int i = s0 + lane;
+              uint32_t c = 0, f = 0;
+              bool alive = false, iso = false;
+              if (i < e) {
+                c = order[i];
+                const int cc = static_cast<int>(c);
+                const int wU = cc - nh > 0 ? cc - nh : 0, wD = cc + nh < C ? cc + nh : C - 1;
+                const int wL = cc > 0 ? cc - 1 : 0, wR = cc + 1 < C ? cc + 1 : C - 1;
+                f = flags[cc];
+                const uint32_t fU = flags[wU], fD = flags[wD], fL = flags[wL], fR = flags[wR];
+                alive = (f & F_UNASSIGNED) != 0;
+                // a neighbour that is unassigned and whose in-edge bit for this cell's side is set can be activated from
+                // here; clamped (non-existent) neighbours can only make a cell look connected, never isolated
+                const uint32_t out = ((fU & (fU >> 3)) | (fD & (fD >> 2)) | (fL & (fL >> 5)) | (fR & (fR >> 4))) & 1u;
+                iso = alive && out == 0u && iso_ok;
+              }
+              const unsigned long long am = __ballot(alive);
+              if (am) {
+                const int first = __builtin_ctzll(am);
+                seed = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c), first));
+                committed = ((__ballot(iso) >> first) & 1ull) != 0ull;
+                if (committed && lane == first) {
+                  queue[tail] = static_cast<idx_t>(c);
+                  qpos[c] = static_cast<idx_t>(tail);
+                  flags[c] = static_cast<uint8_t>(f & ~F_UNASSIGNED);
+                  grow_start[ngrow] = static_cast<uint32_t>(tail);
+                  atomicSub(&hist[bb], 1);
+                }
+                s0 += first + 1;
+                break;
+              }
+              s0 += 64;
+            }
+            if (lane == 0) bin_start[bb] = static_cast<idx_t>(s0 < e ? s0 : e);
+            if (committed) {
+              ++tail;
+              ++ngrow;
+              --remaining;
+              wave_sync();
+              if (DBG) {
+                const unsigned long long tc2 = DPX_STAMP();
+                a_argmax += tb - ta; a_seed += tc2 - tb;
+              }
+              st = 0;
+              break;
+            }
+          }
+          if (seed == 0xFFFFFFFFu) break;
+
+          tc = DPX_STAMP();
+          gstart = tail;
+          if (lane == 0) {
+            queue[tail] = static_cast<idx_t>(seed);
+            qpos[seed] = static_cast<idx_t>(tail);
+            flags[seed] = static_cast<uint8_t>(flags[seed] & ~F_UNASSIGNED);
+            atomicSub(&hist[bb], 1);  // hist.removePoint(seed); the seed's bin is bb
+          }
+          ++tail;
+          head = gstart;
+          in_grow = true;
+          st = 0;
+          wave_sync();
+          while (head < tail) {
+            if constexpr (GST) {
+              if (tail - head >= kWideSlots) {
+                st = 1;
+                break;
+              }
+            }
+            // Branch-free step: lane = (slot, dir).  All reads are unconditional (clamped addresses), the decision is
+            // pure bit arithmetic: a single wave issues one instruction per ~4-8 cycles, so instruction count is latency.
+            const int nslots = (tail - head) < 16 ? (tail - head) : 16;
+            const bool active = slot < nslots;
+            const int qi = head + (active ? slot : 0);
+            const uint32_t uh = static_cast<uint32_t>(head), us = static_cast<uint32_t>(slot);
+            const int u = queue[qi];
+            const int vraw = u + delta;
+            const bool inrange = active && (vraw >= 0) && (vraw < C);
+            const int v = vraw < 0 ? 0 : (vraw >= C ? C - 1 : vraw);
+            const uint32_t fv = flags[v];
+            // positions of v's four neighbours in the queue (kNoPos = never activated); out-of-grid neighbours are
+            // clamped to a valid address and are harmless because v's in-edge bit for them is 0 (k_cellgraph)
+            const int wU = v - nh > 0 ? v - nh : 0, wD = v + nh < C ? v + nh : C - 1;
+            const int wL = v - 1 > 0 ? v - 1 : 0, wR = v + 1 < C ? v + 1 : C - 1;
+            const uint32_t qU = qpos[wU], qD = qpos[wD], qL = qpos[wL], qR = qpos[wR];
+            // v's bin, needed only if v is activated, is fetched with the reads above instead of after the decision
+            const int bin_v = (FULL ? static_cast<int>(binof[v]) : static_cast<int>(meta[v] >> META_BIN_SHIFT)) - 1;
+            // bit k set: v's neighbour k sits EARLIER in this FIFO batch (queue position in [batch head, batch head + slot))
+            const uint32_t earlier = (((qU - uh) < us) ? 1u : 0u) | (((qD - uh) < us) ? 2u : 0u) |
+                                     (((qL - uh) < us) ? 4u : 0u) | (((qR - uh) < us) ? 8u : 0u);
+            const uint32_t inb = (fv >> 2) & 0xFu;  // in-edge bits of v
+            // u is v's neighbour number dir^1: v accepts u iff that in-edge is set; u loses to any OTHER in-neighbour
+            // that is earlier in the batch.  Integer logic only (no short-circuit): keeps the reads above in one
+            // batch instead of three dependent round trips.
+            const uint32_t okbits = (inrange ? 1u : 0u) & fv & (inb >> opp) & (((inb & earlier & notme) == 0u) ? 1u : 0u);
+            const bool win = okbits != 0u;
+            const unsigned long long mask = __ballot(win);
+            if (win) {
+              const int pos = tail + __popcll(mask & lt_mask);
+              queue[pos] = static_cast<idx_t>(v);
+              qpos[v] = static_cast<idx_t>(pos);
+              flags[v] = static_cast<uint8_t>(fv & ~F_UNASSIGNED);
+              if (bin_v >= 0 && bin_v < nb) atomicSub(&hist[bin_v], 1);  // hist.removePoint at activation time
+            }
+            tail += __popcll(mask);
+            head += nslots;
+            if constexpr (GST) {
+              wave_sync();  // queue / queue positions in global memory: the next step's loads must see these stores
+            } else {
+              // LDS executes a wave's operations in order, so the next step's reads see this step's writes without
+              // waiting for them to retire; only the compiler has to keep the order
+              asm volatile("" ::: "memory");
+              __builtin_amdgcn_wave_barrier();
+            }
+            if (DBG) ++n_steps;
+          }
+        } while (false);
+        if (st != 0) break;
+        if (in_grow) finish_grow();
+        }
+      }
+      if constexpr (GST) {
+        int* ctl = hdr + 8 + 4 * (round & 1);  // two sets: a wave may still be reading the previous round's
+        if (tid == 0) {
+          ctl[0] = st;
+          ctl[1] = head;
+          ctl[2] = tail;
+        }
+        __syncthreads();
+        st = ctl[0];
+        if (st == 2) break;
+        if (st == 1) {
+          int H = ctl[1], T = ctl[2];
+          int* wc = hdr + 24;  // per-wave winner counts of the current batch
+          while (H < T) {
+            const int ns = (T - H) < 16 * kRW ? (T - H) : 16 * kRW;
+            const int gs = wid * 16 + slot;  // slot of this lane's queue entry within the batch
+            const bool active = gs < ns;
+            const int qi = H + (active ? gs : 0);
+            const uint32_t uh = static_cast<uint32_t>(H), us = static_cast<uint32_t>(gs);
+            const int u = queue[qi];
+            const int vraw = u + delta;
+            const bool inrange = active && (vraw >= 0) && (vraw < C);
+            const int v = vraw < 0 ? 0 : (vraw >= C ? C - 1 : vraw);
+            const uint32_t fv = flags[v];
+            // positions of v's four neighbours in the queue (kNoPos = never activated); out-of-grid neighbours are
+            // clamped to a valid address and are harmless because v's in-edge bit for them is 0 (k_cellgraph)
+            const int wU = v - nh > 0 ? v - nh : 0, wD = v + nh < C ? v + nh : C - 1;
+            const int wL = v - 1 > 0 ? v - 1 : 0, wR = v + 1 < C ? v + 1 : C - 1;
+            const uint32_t qU = qpos[wU], qD = qpos[wD], qL = qpos[wL], qR = qpos[wR];
+            // v's bin, needed only if v is activated, is fetched with the reads above instead of after the decision
+            const int bin_v = (FULL ? static_cast<int>(binof[v]) : static_cast<int>(meta[v] >> META_BIN_SHIFT)) - 1;
+            // bit k set: v's neighbour k sits EARLIER in this FIFO batch (queue position in [batch head, batch head + slot))
+            const uint32_t earlier = (((qU - uh) < us) ? 1u : 0u) | (((qD - uh) < us) ? 2u : 0u) |
+                                     (((qL - uh) < us) ? 4u : 0u) | (((qR - uh) < us) ? 8u : 0u);
+            const uint32_t inb = (fv >> 2) & 0xFu;  // in-edge bits of v
+            // u is v's neighbour number dir^1: v accepts u iff that in-edge is set; u loses to any OTHER in-neighbour
+            // that is earlier in the batch.  Integer logic only (no short-circuit): keeps the reads above in one
+            // batch instead of three dependent round trips.
+            const uint32_t okbits = (inrange ? 1u : 0u) & fv & (inb >> opp) & (((inb & earlier & notme) == 0u) ? 1u : 0u);
+            const bool win = okbits != 0u;
+            const unsigned long long mask = __ballot(win);
+            if (lane == 0) wc[wid] = __popcll(mask);
+            __syncthreads();
+            int off = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < kRW; ++w) {
+              const int cw = wc[w];
+              off += w < wid ? cw : 0;
+              tot += cw;
+            }
+            if (win) {
+              const int pos = T + off + __popcll(mask & lt_mask);
+              queue[pos] = static_cast<idx_t>(v);
+              qpos[v] = static_cast<idx_t>(pos);
+              flags[v] = static_cast<uint8_t>(fv & ~F_UNASSIGNED);
+              if (bin_v >= 0 && bin_v < nb) atomicSub(&hist[bin_v], 1);
+            }
+            T += tot;
+            H += ns;
+            if (DBG) ++n_steps;
+            __syncthreads();  // this batch's queue / position / flag writes are visible before the next batch reads
+          }
+          tail = T;
+        }
+      } else {
+        if (st == 2) break;
+      }
+      if (wid == 0) {  // (tier 0 only gets here: the wide BFS of wave 0's current grow just finished)
+        finish_grow();
+        ++guard;
+      }
     }
-    if (lane == 0) {
+    if (wid == 0 && lane == 0) {
       grow_start[ngrow] = static_cast<uint32_t>(tail);
       hdr[1] = tail;
       hdr[2] = ngrow;
