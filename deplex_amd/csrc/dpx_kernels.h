@@ -503,7 +503,16 @@ __global__ __launch_bounds__(256) void k_labels_rows(Params prm, const int32_t* 
           ++cc;
         }
       }
-      for (int r = row_begin; r < row_end; ++r) *reinterpret_cast<int4*>(dst + static_cast<long long>(r) * prm.W + col) = v;
+      // streaming stores: the label map is written once and not read again by this pipeline
+      for (int r = row_begin; r < row_end; ++r) {
+#ifdef DPX_LABELS_PLAIN_STORE
+        *reinterpret_cast<int4*>(dst + static_cast<long long>(r) * prm.W + col) = v;
+#else
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        const i32x4 nv = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(nv, reinterpret_cast<i32x4*>(dst + static_cast<long long>(r) * prm.W + col));
+#endif
+      }
     }
     if (prm.nh <= 1024) break;
   }
