@@ -214,7 +214,13 @@ def main():
         ref = O.process_depth_batch(O.default_config(), depth[:nchk], *intr, threads=min(nchk, os.cpu_count() or 1))
         if not np.array_equal(got, ref):
             raise SystemExit("bench: HIP label maps differ from the oracle — refusing to report a number")
-        parity = f"bit-exact label maps vs oracle on {nchk} frames"
+        # every step processed the same frames: all output buffers of the in-flight window must hold the same bits
+        # (catches a slot being reused before its previous submission finished)
+        nbuf = min(args.steps + args.warmup, S * G)
+        same = all(bool(torch.equal(d_labels[k], d_labels[0])) for k in range(1, nbuf))
+        if not same:
+            raise SystemExit("bench: output buffers of different in-flight submissions differ — refusing to report a number")
+        parity = f"bit-exact label maps vs oracle on {nchk} frames; {nbuf} in-flight output buffers identical"
 
     if rank == 0:
         total_frames = B * args.steps * world
