@@ -216,7 +216,7 @@ def main():
             raise SystemExit("bench: HIP label maps differ from the oracle — refusing to report a number")
         # every step processed the same frames: all output buffers of the in-flight window must hold the same bits
         # (catches a slot being reused before its previous submission finished)
-        nbuf = min(args.steps + args.warmup, S * G)
+        nbuf = min(max(args.steps, args.warmup), S * G)  # (warm-up and timed steps both index the buffers from 0)
         same = all(bool(torch.equal(d_labels[k], d_labels[0])) for k in range(1, nbuf))
         if not same:
             raise SystemExit("bench: output buffers of different in-flight submissions differ — refusing to report a number")

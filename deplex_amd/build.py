@@ -41,5 +41,34 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     return OUT
 
 
+PYB_SRC = PKG / "cpp" / "pybind" / "deplex_pybind.cpp"
+
+
+def pybind_path() -> Path:
+    import sysconfig
+    return PKG / ("_pybind" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_pybind(force: bool = False, verbose: bool = False) -> Path:
+    """pybind11 module with the reference's binding surface (deplex_amd/cpp/pybind), g++ against libdeplex_amd.so."""
+    import sysconfig
+    import pybind11
+    out = pybind_path()
+    deps = [PYB_SRC, PKG.parent / "include" / "deplex_amd.h", *(PKG / "cpp" / "include" / "deplex").rglob("*.h")]
+    if not force and out.exists() and all(d.stat().st_mtime <= out.stat().st_mtime for d in deps):
+        return out
+    build()  # the module links against the HIP library
+    tmp = out.with_suffix(".tmp")
+    cmd = ["g++", "-O2", "-shared", "-fPIC", "-std=c++17", "-fvisibility=hidden",
+           f"-I{sysconfig.get_paths()['include']}", f"-I{pybind11.get_include()}", str(PYB_SRC),
+           f"-L{OUT.parent}", "-ldeplex_amd", "-Wl,-rpath,$ORIGIN/lib", "-o", str(tmp)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    os.replace(tmp, out)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_pybind(force=True, verbose=True))

@@ -428,6 +428,26 @@ def test_multistream_pipeline(D, oracle):
         del pipe
 
 
+def test_pybind_module_known_answer(D, oracle, tum_depth):
+    """README usage through the compiled binding surface (python/tests/test_plane_extraction.py:44-52): 34 planes on the
+    TUM frame; float64 clouds are accepted; same bits as the ctypes mirror and the oracle."""
+    from deplex_amd.pybind import plane_extraction, utils
+    K = synth.read_K(synth.TUM_K)
+    image = utils.DepthImage(str(synth.TUM_PNG))
+    pcd = image.transform_to_pcd(K.astype(np.float32))
+    assert pcd.shape == (480 * 640, 3) and pcd.dtype == np.float32 and pcd[:, 2].max() == 46655
+    ex = plane_extraction.PlaneExtractor(image_height=image.height, image_width=image.width, config=plane_extraction.Config())
+    labels = ex.process(pcd_array=pcd)
+    assert labels.dtype == np.int32 and labels.shape == (480 * 640,) and labels.max() == 34
+    assert sha(labels) == GOLD["tum_f32_default"]["sha256"]
+    assert np.array_equal(ex.process(pcd.astype(np.float64)), labels)
+    assert ex.planes().shape == (34, 10)
+    with pytest.raises(RuntimeError, match="Number of points doesn't match image shape"):
+        ex.process(pcd[:100])
+    ex2 = plane_extraction.PlaneExtractor(480, 640)  # default config argument
+    assert np.array_equal(ex2.process(pcd), labels)
+
+
 def test_debug_dumps(D, oracle, tum_depth, tmp_path):
     """The DEBUG_DEPLEX stage CSVs of the reference (plane_extractor.cpp:204-263): same names, same layout."""
     K = synth.read_K(synth.TUM_K)

@@ -139,3 +139,26 @@ def test_cpp_mirror_compiles_and_reports_errors(tmp_path):
     r = subprocess.run([str(exe), str(raw), "8", "8", str(synth.TUM_K)], capture_output=True, text=True)
     if r.returncode != 0:  # CPU-only container: no HIP device -> std::runtime_error from dpx_backproject/dpx_create
         assert "no HIP device" in r.stderr or "hip" in r.stderr.lower()
+
+
+def test_pybind_surface_matches_reference():
+    """cpp/pybind/deplex_pybind.cpp:19-25, plane_extraction.cpp:28-37, utils/utils.cpp:29-36: module layout, class and
+    argument names of the compiled binding; construction errors carry the reference's texts (no GPU needed)."""
+    import importlib
+    import pytest
+    pyb = importlib.import_module("deplex_amd.pybind")
+    pe = importlib.import_module("deplex_amd.pybind.plane_extraction")
+    ut = importlib.import_module("deplex_amd.pybind.utils")
+    assert pyb.plane_extraction is pe and pyb.utils is ut
+    assert {"Config", "PlaneExtractor"} <= set(dir(pe)) and "DepthImage" in dir(ut)
+    assert "path" in pe.Config.__init__.__doc__ and "image_height" in pe.PlaneExtractor.__init__.__doc__
+    assert "config" in pe.PlaneExtractor.__init__.__doc__ and "pcd_array" in pe.PlaneExtractor.process.__doc__
+    assert "intrinsics" in ut.DepthImage.transform_to_pcd.__doc__ and "image_path" in ut.DepthImage.reset.__doc__
+    with pytest.raises(RuntimeError, match="Couldn't open ini file: /no/such.ini"):
+        pe.Config("/no/such.ini")
+    cfg = pe.Config(str(synth.ICL_INI))
+    assert cfg.patch_size == 4
+    img = ut.DepthImage(str(synth.TUM_PNG))
+    assert (img.height, img.width) == (480, 640)
+    img.reset(str(synth.ICL_PNG))
+    assert (img.height, img.width) == (480, 640)
