@@ -207,7 +207,8 @@ def test_config_variants(D, oracle):
     depth = synth.synth_batch(2, 240, 320, seed0=5)
     intr = synth.intrinsics_for(240, 320)
     for ov in ({"min_region_growing_cells_activated": 1, "min_region_growing_candidate_size": 1},
-               {"min_pts_per_cell": 6}, {"histogram_bins_per_coord": 7}, {"max_number_depth_discontinuity": 3},
+               {"min_pts_per_cell": 6}, {"histogram_bins_per_coord": 7}, {"histogram_bins_per_coord": 60},
+               {"max_number_depth_discontinuity": 3},
                {"min_cos_angle_merge": 0.99, "max_merge_dist": 50.0}, {"min_region_planarity_score": 0.9},
                {"min_region_growing_candidate_size": -1}, {"min_region_growing_cells_activated": -1}):
         full_compare(D, oracle, depth, intr, oracle.default_config(**ov))
@@ -426,6 +427,23 @@ def test_multistream_pipeline(D, oracle):
         for i in range(5):
             assert np.array_equal(d_out[i].cpu().numpy(), refs[i]), f"group {group} mixed-form batch {i}"
         del pipe
+
+
+def test_host_batches_with_records(D, oracle):
+    """Larger host-pointer batches (depth, cloud, lean tier, refinement): labels, per-frame records and statistics of
+    every frame."""
+    K = synth.read_K(synth.TUM_K)
+    intr = tuple(float(v) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2]))
+    full_compare(D, oracle, synth.tum_stream(19), intr, oracle.default_config())
+    depth = synth.synth_batch(9, 240, 320, seed0=21)
+    full_compare(D, oracle, depth, synth.intrinsics_for(240, 320), oracle.default_config(), xyz_api=True)
+    os.environ["DPX_REGIONS_LEAN"] = "1"
+    try:
+        full_compare(D, oracle, depth, synth.intrinsics_for(240, 320), oracle.default_config())
+    finally:
+        del os.environ["DPX_REGIONS_LEAN"]
+    cfg = oracle.default_config(ransac_refinement=1)
+    full_compare(D, oracle, synth.synth_batch(8, 120, 160, seed0=5), synth.intrinsics_for(120, 160), cfg)
 
 
 def test_pybind_module_known_answer(D, oracle, tum_depth):
