@@ -446,6 +446,35 @@ def test_host_batches_with_records(D, oracle):
     full_compare(D, oracle, synth.synth_batch(8, 120, 160, seed0=5), synth.intrinsics_for(120, 160), cfg)
 
 
+def test_instances_are_independent_across_host_threads(D, oracle):
+    """SURVEY 8(b) threading contract: an instance is not re-entrant, distinct instances are independent.  Four host
+    threads, one extractor each, different frames, concurrent calls (ctypes releases the GIL)."""
+    import threading
+    h, w = 240, 320
+    intr = synth.intrinsics_for(h, w)
+    jobs = [synth.synth_batch(3, h, w, seed0=70 + 5 * t) for t in range(4)]
+    oracle.set_math("devmath")
+    refs = [oracle.process_depth_batch(oracle.default_config(), j, *intr, threads=2) for j in jobs]
+    out, errs = [None] * 4, []
+
+    def work(t):
+        try:
+            ex = D.PlaneExtractor(h, w, max_batch=3)
+            for _ in range(5):
+                out[t] = ex.process_depth_batch(jobs[t], *intr)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for t in range(4):
+        assert np.array_equal(out[t], refs[t]), f"thread {t}"
+
+
 def test_pybind_module_known_answer(D, oracle, tum_depth):
     """README usage through the compiled binding surface (python/tests/test_plane_extraction.py:44-52): 34 planes on the
     TUM frame; float64 clouds are accepted; same bits as the ctypes mirror and the oracle."""
