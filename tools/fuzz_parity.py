@@ -1,0 +1,55 @@
+"""Randomised parity sweep: random image sizes, patch sizes, configurations, input forms and kernel tiers against the
+oracle (labels, cell records, plane records, statistics).  usage: fuzz_parity.py [cases] [seed]"""
+import os, sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import numpy as np
+import synth
+import deplex_amd as D
+from oracle import oracle as O
+import test_gpu_parity as T
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t0 = time.time()
+fails = 0
+for it in range(cases):
+    P = int(rng.choice([4, 8, 10, 10, 10, 6, 5, 7, 12, 16]))
+    big = rng.random() < 0.1
+    nh, nv = int(rng.integers(1, 200 if big else 90)), int(rng.integers(1, 130 if big else 60))
+    w = nh * P + int(rng.choice([0, 0, 0, 1, 2, 3]))
+    h = nv * P + int(rng.choice([0, 0, 1, P - 1]))
+    ov = {"patch_size": P}
+    if rng.random() < 0.5:
+        ov["histogram_bins_per_coord"] = int(rng.choice([3, 7, 20, 33, 60]))
+    if rng.random() < 0.3:
+        ov["min_cos_angle_merge"] = float(rng.choice([0.8, 0.93, 0.99]))
+    if rng.random() < 0.3:
+        ov["min_region_growing_cells_activated"] = int(rng.choice([1, 2, 8]))
+    if rng.random() < 0.3:
+        ov["min_region_growing_candidate_size"] = int(rng.choice([1, 3, 10]))
+    if rng.random() < 0.2:
+        ov["min_region_planarity_score"] = float(rng.choice([0.3, 0.8]))
+    if rng.random() < 0.15:
+        ov["ransac_refinement"] = 1
+    env = str(rng.choice(["", "", "DPX_REGIONS_LEAN", "DPX_REGIONS_GSTATE", "DPX_REGIONS_NOSPLIT", "DPX_FUSED_LABELS", "DPX_REGIONS_V1"]))
+    xyz = bool(rng.random() < 0.3)
+    B = int(rng.integers(1, 4))
+    seed = int(rng.integers(0, 10000))
+    kw = dict(noise=bool(rng.random() < 0.8), dropout=bool(rng.random() < 0.8), scale=float(rng.choice([1.0, 5.0])))
+    depth = np.stack([synth.synth_depth(h, w, seed=seed + k, **kw) for k in range(B)])
+    if env:
+        os.environ[env] = "1"
+    try:
+        T.full_compare(D, O, depth, synth.intrinsics_for(h, w), O.default_config(**ov), xyz_api=xyz)
+    except Exception as e:  # noqa: BLE001
+        fails += 1
+        print(f"FAIL case {it}: {h}x{w} P={P} B={B} seed={seed} env={env} xyz={xyz} ov={ov} kw={kw}: {type(e).__name__}: {str(e)[:200]}", flush=True)
+    finally:
+        if env:
+            del os.environ[env]
+    if it % 20 == 19:
+        print(f"{it + 1} cases, {fails} failures, {time.time() - t0:.0f} s", flush=True)
+print(f"done: {cases} cases, {fails} failures")
+sys.exit(1 if fails else 0)
