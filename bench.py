@@ -87,8 +87,8 @@ def cpu_baseline(depth, intr, cores: int, budget_s: float = 15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DPX_BENCH_STREAMS", 16)))
     ap.add_argument("--group", type=int, default=int(os.environ.get("DPX_BENCH_GROUP", 8)), help="submissions per region-growing launch")
