@@ -99,7 +99,7 @@ __host__ __device__ inline R2Layout r2_layout(int tier, int C, int nb) {
 }
 
 struct Regions2Extra {
-  const float* mse_c;   // [B][C] compact per-cell mse (k_cellgraph output)
+  const float* mse_c;   // [B][C] compact per-cell mse (k_cellgraph output; read by dpx_binsort.h, not by k_regions2)
   uint32_t* cand_grow;  // [B][pcap] grow index of each candidate segment
   unsigned long long* dbg;  // diagnostic build only: [B][16] shader-clock stamps / sums
   float4* lds_img;          // split mode: [B][img_bytes] image of the workgroup's LDS handed from phase to phase
@@ -175,7 +175,6 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
 
   const dpx_cell* cells = rb.cells + static_cast<size_t>(frame) * C;
   const uint32_t* meta = rb.meta + static_cast<size_t>(frame) * C;
-  const float* mse_c = rx.mse_c + static_cast<size_t>(frame) * C;
   uint32_t* grow_start = rb.grow_start + static_cast<size_t>(frame) * (C + 1);
   uint32_t* cand_grow = rx.cand_grow + static_cast<size_t>(frame) * rb.pcap;
   float* cand = rb.cand + static_cast<size_t>(frame) * rb.pcap * 12;
