@@ -255,6 +255,13 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "bytes_per_launch": pf_bytes, "avg_launch_ms": round(pf_ms, 4),
+                         # the kernel's actual bound: VALU issue.  23.3 instructions per pixel in the
+                         # ISA of the exact moment arithmetic + ~1070 per 64-cell wave for the f64 plane fit, against one
+                         # wave-instruction per 4 cycles per SIMD (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz)
+                         "valu": {"lane_ops_per_launch": int(B * (23.3 * N + 1070 * (W // 10) * (H // 10))),
+                                  "achieved_Tops": round(B * (23.3 * N + 1070 * (W // 10) * (H // 10)) / (pf_ms * 1e-3) / 1e12, 2),
+                                  "issue_peak_Tops": 39.3,
+                                  "frac": round(B * (23.3 * N + 1070 * (W // 10) * (H // 10)) / (pf_ms * 1e-3) / 39.3e12, 3)},
                          "measured": f"{args.roofline_iters} launches back to back on one stream after the timed region, HIP events on that stream",
                          "in_pipeline": {"avg_launch_ms": round(kms["planefit"], 4), "achieved": round(in_pipe, 1),
                                          "note": f"HIP events around the launches of the timed steps with {S} groups of {G} batches in flight (includes queueing behind / sharing with the other batches' kernels)"}},
