@@ -664,25 +664,44 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
       const int gs = static_cast<int>(grow_start[gi]), ge = static_cast<int>(grow_start[gi + 1]);
       const int comp = lane < 9 ? lane : 0;
       float acc = reinterpret_cast<const float*>(cells)[static_cast<size_t>(queue[gs]) * 16 + comp];  // the seed, counted twice
+      // the records of the NEXT 32 cells are fetched while the 9 chains run over the current 32 (the chains are
+      // sequential by definition, the gathers are not)
+      float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa, pc = pa;
+      if (gs + lane < ge && lane < kStage) {
+        const size_t v = queue[gs + lane];
+        pa = cf4[v * 4 + 0]; pb = cf4[v * 4 + 1]; pc = cf4[v * 4 + 2];
+      }
       for (int base = gs; base < ge; base += kStage) {
         const int cnt = (ge - base) < kStage ? (ge - base) : kStage;
-        if (lane < cnt) {
-          const size_t v = queue[base + lane];
-          const float4 a = cf4[v * 4 + 0], b4 = cf4[v * 4 + 1], c4 = cf4[v * 4 + 2];
-          float* d = st + lane * 9;
-          d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b4.x; d[5] = b4.y; d[6] = b4.z; d[7] = b4.w; d[8] = c4.x;
+        if (lane < cnt) {  // staging is component-major: st[comp][entry], so a chain reads its 32 values as 8 x 16 bytes
+          float* d = st + lane;
+          d[0 * kStage] = pa.x; d[1 * kStage] = pa.y; d[2 * kStage] = pa.z; d[3 * kStage] = pa.w; d[4 * kStage] = pb.x;
+          d[5 * kStage] = pb.y; d[6 * kStage] = pb.z; d[7 * kStage] = pb.w; d[8 * kStage] = pc.x;
         }
         wave_sync();
-        if (lane < 9) {
-          int e2 = 0;
-          for (; e2 + 8 <= cnt; e2 += 8) {
-            float t[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) t[q] = st[(e2 + q) * 9 + comp];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) acc = acc + t[q];
+        {
+          const int nx = base + kStage + lane;
+          if (nx < ge && lane < kStage) {
+            const size_t v = queue[nx];
+            pa = cf4[v * 4 + 0]; pb = cf4[v * 4 + 1]; pc = cf4[v * 4 + 2];
           }
-          for (; e2 < cnt; ++e2) acc = acc + st[e2 * 9 + comp];
+        }
+        if (lane < 9) {
+          const float4* row = reinterpret_cast<const float4*>(st + comp * kStage);
+          float t[kStage];
+#pragma unroll
+          for (int q = 0; q < kStage / 4; ++q) {
+            const float4 x = row[q];
+            t[4 * q] = x.x; t[4 * q + 1] = x.y; t[4 * q + 2] = x.z; t[4 * q + 3] = x.w;
+          }
+          if (cnt == kStage) {
+#pragma unroll
+            for (int q = 0; q < kStage; ++q) acc = acc + t[q];
+          } else {
+#pragma unroll
+            for (int q = 0; q < kStage; ++q)
+              if (q < cnt) acc = acc + t[q];
+          }
         }
         wave_sync();
       }
