@@ -104,6 +104,18 @@ def test_tum_python_test_path(D, tum_depth):
     assert sha(labels) == GOLD["tum_f64_default"]["sha256"]
 
 
+def test_plane_parameters_against_committed_goldens(D, tum_depth, icl_depth):
+    """The HIP path's plane records against tests/golden/plane_goldens.json (glibc-flavour oracle): within 1e-5."""
+    from test_oracle import _plane_gold, assert_planes_close
+    for name, depth, Kp, cfg in (("tum_f32_default", tum_depth, synth.TUM_K, D.Config()),
+                                 ("icl_default", icl_depth, synth.ICL_K, D.Config()),
+                                 ("icl_ini", icl_depth, synth.ICL_K, D.Config(str(synth.ICL_INI)))):
+        K = synth.read_K(Kp)
+        ex = D.PlaneExtractor(480, 640, cfg)
+        ex.process_depth_batch(depth[None], float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]))
+        assert_planes_close(ex.planes(0), _plane_gold(name))
+
+
 def test_fixtures_full_parity(D, oracle, tum_depth, icl_depth):
     Kt, Ki = synth.read_K(synth.TUM_K), synth.read_K(synth.ICL_K)
     it = tuple(float(v) for v in (Kt[0, 0], Kt[1, 1], Kt[0, 2], Kt[1, 2]))

@@ -227,3 +227,40 @@ def test_refinement_reduces_plane_mse(oracle, tum_depth, icl_depth, which):
     assert mse(refined) <= mse(coarse)
     assert set(np.unique(refined)) <= set(np.unique(coarse))  # refinement only removes pixels from planes
     assert np.all((refined == coarse) | (refined == 0))
+
+
+def _plane_gold(name):
+    import json
+    g = json.loads((synth.GOLDEN.parent / "plane_goldens.json").read_text())["frames"][name]
+    f = lambda u: np.array(u, dtype=np.uint32).view(np.float32)  # noqa: E731
+    return {"normal": np.stack([f(p["normal"]) for p in g]), "d": f([p["d"] for p in g]), "mse": f([p["mse"] for p in g]),
+            "score": f([p["score"] for p in g]), "n_pts": np.array([p["n_pts"] for p in g]),
+            "merge_label": np.array([p["merge_label"] for p in g])}
+
+
+def assert_planes_close(planes, gold, tol=1e-5):
+    """north_star: fitted plane parameters within 1e-5 (relative to the parameter's magnitude, absolute below 1)."""
+    assert len(planes) == len(gold["d"])
+    assert np.array_equal(planes["n_pts"], gold["n_pts"]) and np.array_equal(planes["merge_label"], gold["merge_label"])
+    assert np.abs(planes["normal"] - gold["normal"]).max() <= tol
+    for k in ("d", "mse", "score"):
+        assert np.all(np.abs(planes[k] - gold[k]) <= tol * np.maximum(1.0, np.abs(gold[k]))), k
+
+
+@pytest.mark.parametrize("name", ["tum_f32_default", "icl_default", "icl_ini"])
+def test_plane_parameter_goldens(oracle, tum_depth, icl_depth, name):
+    """Committed plane records (tests/golden/plane_goldens.json, float32 bit patterns from the glibc flavour): the
+    glibc flavour reproduces them bit for bit, the device-maths flavour (what the HIP kernels compute) within 1e-5."""
+    depth, Kp = (tum_depth, synth.TUM_K) if name.startswith("tum") else (icl_depth, synth.ICL_K)
+    K = synth.read_K(Kp)
+    cfg = oracle.config_from_ini(synth.ICL_INI) if name == "icl_ini" else oracle.default_config()
+    xyz = oracle.backproject(depth, K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+    gold = _plane_gold(name)
+    oracle.set_math("glibc")
+    _, _, pl, _, _ = oracle.process(cfg, 480, 640, xyz, debug=True)
+    for k in ("normal", "d", "mse", "score"):
+        assert np.array_equal(pl[k].view(np.uint32), gold[k].view(np.uint32)), k
+    oracle.set_math("devmath")
+    _, _, pl, _, _ = oracle.process(cfg, 480, 640, xyz, debug=True)
+    oracle.set_math("glibc")
+    assert_planes_close(pl, gold)

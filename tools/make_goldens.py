@@ -40,22 +40,33 @@ def row(name, labels, st):
             **{k: int(st[k]) for k in ("planar_cells", "grows", "activations", "max_grow", "segments", "merges")}}
 
 
+def plane_rows(planes):
+    """Fitted plane records as float32 bit patterns (exact) — pins the "plane parameters within 1e-5" half of the bar."""
+    return [{"normal": [int(np.float32(v).view(np.uint32)) for v in p["normal"]], "d": int(np.float32(p["d"]).view(np.uint32)),
+             "mse": int(np.float32(p["mse"]).view(np.uint32)), "score": int(np.float32(p["score"]).view(np.uint32)),
+             "n_pts": int(p["n_pts"]), "merge_label": int(p["merge_label"])} for p in planes]
+
+
 def main():
     O.set_math("glibc")
     rows = []
+    plane_gold = {}
     tum = synth.load_png_u16(synth.TUM_PNG)
     icl = synth.load_png_u16(synth.ICL_PNG)
     Kt, Ki = synth.read_K(synth.TUM_K), synth.read_K(synth.ICL_K)
     xyz = O.backproject(tum, Kt[0, 0], Kt[1, 1], Kt[0, 2], Kt[1, 2])
-    l, _, _, _, st = O.process(O.default_config(), 480, 640, xyz, debug=True)
+    l, _, pl, _, st = O.process(O.default_config(), 480, 640, xyz, debug=True)
     rows.append(row("tum_f32_default", l, st))
+    plane_gold["tum_f32_default"] = plane_rows(pl)
     l, _, _, _, st = O.process(O.default_config(), 480, 640, f64_backproject(tum, synth.TUM_K), debug=True)
     rows.append(row("tum_f64_default", l, st))
     xyz = O.backproject(icl, Ki[0, 0], Ki[1, 1], Ki[0, 2], Ki[1, 2])
-    l, _, _, _, st = O.process(O.default_config(), 480, 640, xyz, debug=True)
+    l, _, pl, _, st = O.process(O.default_config(), 480, 640, xyz, debug=True)
     rows.append(row("icl_default", l, st))
-    l, _, _, _, st = O.process(O.config_from_ini(synth.ICL_INI), 480, 640, xyz, debug=True)
+    plane_gold["icl_default"] = plane_rows(pl)
+    l, _, pl, _, st = O.process(O.config_from_ini(synth.ICL_INI), 480, 640, xyz, debug=True)
     rows.append(row("icl_ini", l, st))
+    plane_gold["icl_ini"] = plane_rows(pl)
     for (h, w, kw, seeds) in [(240, 320, {}, range(4)), (480, 640, {}, range(4)), (480, 640, {"noise": False}, range(2)),
                               (480, 640, {"scale": 5.0}, range(2)), (960, 1280, {}, range(1))]:
         fx, fy, cx, cy = synth.intrinsics_for(h, w)
@@ -77,6 +88,10 @@ def main():
     out = ROOT / "tests" / "golden" / "oracle_goldens.json"
     out.write_text(json.dumps({"generator": "tools/make_goldens.py (oracle, glibc flavour)", "rows": rows}, indent=1))
     print(f"wrote {out} ({len(rows)} rows)")
+    pout = ROOT / "tests" / "golden" / "plane_goldens.json"
+    pout.write_text(json.dumps({"generator": "tools/make_goldens.py (oracle, glibc flavour); float32 bit patterns",
+                                "frames": plane_gold}, indent=0))
+    print(f"wrote {pout} ({sum(len(v) for v in plane_gold.values())} planes)")
     for r in rows[:4]:
         print(r["name"], r["sha256"][:16], r["max_label"], r["segments"])
 
