@@ -184,7 +184,7 @@ class OracleError(RuntimeError):
         self.code = code
 
 
-def process(cfg: OrcConfig, height: int, width: int, xyz: np.ndarray, debug: bool = False, planes_cap: int = 4096):
+def process(cfg: OrcConfig, height: int, width: int, xyz: np.ndarray, debug: bool = False, planes_cap: int = 0):
     """PlaneExtractor(height, width, cfg).process(xyz).  Returns labels, or (labels, cells, planes, cell_labels,
     stats) with debug=True.  Raises OracleError with the reference's message for its throwing cases."""
     xyz = np.ascontiguousarray(xyz, dtype=np.float32)
@@ -193,6 +193,8 @@ def process(cfg: OrcConfig, height: int, width: int, xyz: np.ndarray, debug: boo
     P = max(cfg.patch_size, 1)
     nh, nv = width // P, height // P
     cells = np.zeros(nh * nv, dtype=CELL_DTYPE) if debug else None
+    if planes_cap <= 0:  # one plane per cell is the most the algorithm can produce
+        planes_cap = max(4096, nh * nv)
     planes = np.zeros(planes_cap, dtype=PLANE_DTYPE) if debug else None
     cl = np.zeros(nh * nv, dtype=np.int32) if debug else None
     stats = np.zeros(1, dtype=STATS_DTYPE)

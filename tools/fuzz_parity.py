@@ -10,6 +10,38 @@ import deplex_amd as D
 from oracle import oracle as O
 import test_gpu_parity as T
 
+import torch
+
+
+def fuzz_pipeline(rng, depth, intr, ocfg, xyz):
+    """The same frames through dpx_pipeline with random slots / group / number of submissions (device buffers)."""
+    B, H, W = depth.shape
+    dev = torch.device("cuda", 0)
+    O.set_math("devmath")
+    refs = []
+    for d in depth:
+        refs.append(O.process(ocfg, H, W, O.backproject(d, *[np.float32(v) for v in intr]), debug=True)[0])
+    ref = np.stack(refs)
+    slots, group, nsub = int(rng.integers(1, 4)), int(rng.integers(1, 5)), int(rng.integers(1, 8))
+    pipe = D.Pipeline(H, W, T.to_cfg(D, ocfg), batch=B, slots=slots, group=group)
+    if xyz:
+        d_in = torch.from_numpy(np.stack([O.backproject(d, *[np.float32(v) for v in intr]) for d in depth])).to(dev)
+    else:
+        d_in = torch.from_numpy(depth.view(np.int16)).to(dev)
+    outs = [torch.full((B, H * W), -1, dtype=torch.int32, device=dev) for _ in range(nsub)]
+    for i in range(nsub):
+        if xyz:
+            pipe.submit_pcd(d_in.data_ptr(), B, outs[i].data_ptr())
+        else:
+            pipe.submit_depth(d_in.data_ptr(), B, *intr, outs[i].data_ptr())
+        if rng.random() < 0.2:
+            pipe.sync()
+    pipe.sync()
+    for i in range(nsub):
+        assert np.array_equal(outs[i].cpu().numpy(), ref), f"pipeline submission {i} (slots {slots}, group {group}, nsub {nsub})"
+    del pipe
+
+
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time()
@@ -42,7 +74,10 @@ for it in range(cases):
     if env:
         os.environ[env] = "1"
     try:
-        T.full_compare(D, O, depth, synth.intrinsics_for(h, w), O.default_config(**ov), xyz_api=xyz)
+        if rng.random() < 0.2 and env not in ("DPX_REGIONS_V1",):
+            fuzz_pipeline(rng, depth, synth.intrinsics_for(h, w), O.default_config(**ov), xyz)
+        else:
+            T.full_compare(D, O, depth, synth.intrinsics_for(h, w), O.default_config(**ov), xyz_api=xyz)
     except Exception as e:  # noqa: BLE001
         fails += 1
         print(f"FAIL case {it}: {h}x{w} P={P} B={B} seed={seed} env={env} xyz={xyz} ov={ov} kw={kw}: {type(e).__name__}: {str(e)[:200]}", flush=True)
