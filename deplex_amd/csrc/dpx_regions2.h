@@ -56,8 +56,11 @@ __device__ __forceinline__ uint32_t ordered_f32(float f) {
 #endif
 constexpr int kRT = DPX_RT;        // threads per frame workgroup
 constexpr int kRW = DPX_RT / 64;   // waves
-constexpr int kStage = 32;         // entries of the per-wave staging buffer of the accumulation phase
-constexpr int kStageFloats = (kRW * kStage * 9 > 2304) ? kRW * kStage * 9 : 2304;  // the merge phase needs 2304 words
+// entries of the per-wave staging buffer of the accumulation phase: 32 where the buffer reuses dead image arrays
+// (tier 2), 64 where it lies behind the image anyway (large frames: fewer, longer chunks per segment)
+__host__ __device__ constexpr int stage_entries(int tier) { return tier == 2 ? 32 : 64; }
+// floats of the staging buffer; the merge phase needs at least 2304 words of it
+__host__ __device__ constexpr int stage_floats(int tier) { return kRW * stage_entries(tier) * 9 > 2304 ? kRW * stage_entries(tier) * 9 : 2304; }
 
 // LDS image of a frame's region-growing state (byte offsets), shared by the device code and the host's size
 // computation.  Everything up to image_end is handed from launch to launch in split mode.  The float staging buffer of
@@ -87,7 +90,7 @@ __host__ __device__ inline R2Layout r2_layout(int tier, int C, int nb) {
     L.order = o; o += 2u * C;
   }
   L.image_end = (o + 15u) & ~15u;
-  const uint32_t stage_bytes = static_cast<uint32_t>(kStageFloats) * 4u;
+  const uint32_t stage_bytes = static_cast<uint32_t>(stage_floats(tier)) * 4u;
   if (dead_end - L.hist >= stage_bytes) {
     L.stage = L.hist;
     L.tail_end = L.image_end;
@@ -657,6 +660,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
   for (int c = tid; c < C; c += kRT) lab16[c] = 0;
   // ---------------- P2: exact float accumulation of every candidate segment (wave per segment) ------------
   {
+    constexpr int kStage = stage_entries(TIER);
     float* st = stage + wid * kStage * 9;
     const float4* cf4 = reinterpret_cast<const float4*>(cells);
     for (int ci = wid; ci < ncand; ci += kRW) {
