@@ -785,8 +785,15 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
   int merges = 0;
   const int wpr = (nplanes + 31) >> 5;  // words per adjacency bit row
   constexpr int kMatWords = 2304;       // stage holds at least 2304 words
-  // (tier 0 keeps the plane views in the LDS flag array, dead by now: C bytes; the other tiers in qpos|queue: 4*C bytes)
-  const bool fast = nplanes * 32 <= (GST ? C : 4 * C) && nplanes * wpr <= kMatWords;
+  // Plane views: tiers 2/1 keep them in qpos|queue (dead, 4*C bytes); tier 0 in the LDS flag array (dead, C bytes),
+  // behind the part of it that the staging buffer (the bit matrix below) overlays.
+  uint32_t pv_off = lay.flags;
+  {
+    const uint32_t stage_end = lay.stage + static_cast<uint32_t>(stage_floats(TIER)) * 4u;
+    if (lay.stage < lay.flags + static_cast<uint32_t>(C) && stage_end > pv_off) pv_off = (stage_end + 3u) & ~3u;
+  }
+  const int pv_room = GST ? (pv_off < lay.flags + static_cast<uint32_t>(C) ? static_cast<int>(lay.flags + C - pv_off) : 0) : 4 * C;
+  const bool fast = nplanes * 32 <= pv_room && nplanes * wpr <= kMatWords;
   const int gw = nh - 1, gh = nv - 1;
   const int gtotal = gw > 0 && gh > 0 ? gw * gh : 0;
   // merge test of the row plane (pnx.., pd) against a column plane (plane_extractor.cpp:405-412)
@@ -798,7 +805,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
   };
   if (nplanes > 0 && fast && wid == 0) {
     uint32_t* mat = reinterpret_cast<uint32_t*>(stage);
-    float* pview = GST ? reinterpret_cast<float*>(smem + lay.flags) : reinterpret_cast<float*>(qpos);  // dead arrays
+    float* pview = GST ? reinterpret_cast<float*>(smem + pv_off) : reinterpret_cast<float*>(qpos);  // dead arrays
     int32_t* lmerge = reinterpret_cast<int32_t*>(pview + 7 * nplanes);
     for (int w = lane; w < nplanes * wpr; w += 64) mat[w] = 0;
     for (int i = lane; i < nplanes; i += 64) {

@@ -29,4 +29,5 @@ for (h, w, B, nuniq) in [(960, 1280, 256, 8), (2160, 3840, 8, 2)]:
     t = time.time()
     ref = O.process_depth_batch(O.default_config(), uniq, *intr, threads=min(nuniq, 8))
     print(f"  oracle {nuniq} frames {time.time()-t:.1f}s; bit-exact: {np.array_equal(got, ref)}; planes {[int(x.max()) for x in got]}", flush=True)
+    assert np.array_equal(got, ref), "label maps differ from the oracle"
     assert np.array_equal(lab[nuniq:2*nuniq].cpu().numpy(), got)
