@@ -62,6 +62,7 @@ struct dpx_handle_s {
   dpx_frame_stats* d_stats = nullptr;
   uint32_t* d_mt_init = nullptr;        // default-seeded mt19937 state for the RANSAC refinement
   size_t refine_lds = 0;
+  int* d_refine_cells = nullptr;        // refinement of frames whose cell list does not fit LDS: [B][C]
   unsigned long long* d_dbg = nullptr;  // diagnostic phase stamps (dpx_debug_region_phases)
   float4* d_lds_img = nullptr;          // split region kernel: LDS image per frame
   bool regions_split = false;
@@ -132,6 +133,7 @@ void free_all(dpx_handle h) {
   hipFree(h->d_sort_keys);
   hipFree(h->d_bin_off);
   hipFree(h->d_gqpos);
+  hipFree(h->d_refine_cells);
   hipFree(h->d_in);
   hipFree(h->d_labels);
   hipFree(h->d_mismatch);
@@ -399,10 +401,16 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
       ra.max_iter = h->cfg.ransac_max_iterations;
       ra.thr = static_cast<double>(h->cfg.ransac_threshold);      // SetParamThreshold(double) <- float config value
       ra.ratio = static_cast<double>(h->cfg.ransac_inliers_ratio);
-      if (depth)
-        hipLaunchKernelGGL(dpx::k_refine<true>, dim3(per_sub), dim3(dpx::kRefT), h->refine_lds, s, ps, ra);
+      ra.g_cells = h->d_refine_cells ? h->d_refine_cells + static_cast<size_t>(j) * per_sub * prm.C : nullptr;
+      if (h->d_refine_cells) {
+        if (depth)
+          hipLaunchKernelGGL((dpx::k_refine<true, true>), dim3(per_sub), dim3(dpx::kRefT), h->refine_lds, s, ps, ra);
+        else
+          hipLaunchKernelGGL((dpx::k_refine<false, true>), dim3(per_sub), dim3(dpx::kRefT), h->refine_lds, s, ps, ra);
+      } else if (depth)
+        hipLaunchKernelGGL((dpx::k_refine<true, false>), dim3(per_sub), dim3(dpx::kRefT), h->refine_lds, s, ps, ra);
       else
-        hipLaunchKernelGGL(dpx::k_refine<false>, dim3(per_sub), dim3(dpx::kRefT), h->refine_lds, s, ps, ra);
+        hipLaunchKernelGGL((dpx::k_refine<false, false>), dim3(per_sub), dim3(dpx::kRefT), h->refine_lds, s, ps, ra);
     }
   }
   if (prof) {
@@ -718,12 +726,20 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
     for (uint32_t i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + i;
     A(dev_alloc(&h->d_mt_init, 624));
     if (rc == DPX_OK && hipMemcpy(h->d_mt_init, mt, sizeof(mt), hipMemcpyHostToDevice) != hipSuccess) rc = fail(DPX_ERR_HIP, "hipMemcpy failed");
-    h->refine_lds = (624 + 32 + 16 + 2 * (static_cast<size_t>(nv) + 1) + C) * 4 + 64;
-    if (h->refine_lds > kLdsLimit) rc = fail(DPX_ERR_CAPACITY, "frame too large for the RANSAC refinement kernel's LDS cell list");
+    const size_t refine_fixed = (624 + 32 + 16 + 2 * (static_cast<size_t>(nv) + 1)) * 4 + 64;
+    h->refine_lds = refine_fixed + C * 4;
+    const char* gc = std::getenv("DPX_REFINE_GCELLS");  // test hook: cell list in global scratch for any frame size
+    if (h->refine_lds > kLdsLimit || (gc && gc[0] == '1')) {  // the label's cell list goes to global scratch
+      h->refine_lds = refine_fixed;
+      A(dev_alloc(&h->d_refine_cells, B * C));
+    }
+    if (h->refine_lds > kLdsLimit) rc = fail(DPX_ERR_CAPACITY, "image too tall for the RANSAC refinement kernel's row tables");
     if (rc == DPX_OK && h->refine_lds > 48 * 1024) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_refine<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->refine_lds)) != hipSuccess ||
-          hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_refine<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->refine_lds)) != hipSuccess)
-        rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
+      const void* fns[4] = {reinterpret_cast<const void*>(dpx::k_refine<true, false>), reinterpret_cast<const void*>(dpx::k_refine<false, false>),
+                            reinterpret_cast<const void*>(dpx::k_refine<true, true>), reinterpret_cast<const void*>(dpx::k_refine<false, true>)};
+      for (const void* fn : fns)
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->refine_lds)) != hipSuccess)
+          rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
     }
   }
   if (rc == DPX_OK && (h->regions_tier == 2 || h->regions_tier == 1)) {

@@ -23,6 +23,7 @@ struct RefineArgs {
   const int32_t* cell_labels;  // [B][C] merged label per cell
   int32_t* labels;             // [B][N] in/out
   const uint32_t* mt_init;     // 624 words: state of a default-seeded mt19937
+  int* g_cells;                // GCELLS instantiation: [B][C] scratch for the current label's cell list
   int max_iter;
   double thr;    // paramThreshold (double of the float config value)
   double ratio;  // paramTargetInliersRatio
@@ -77,7 +78,9 @@ __device__ __forceinline__ void refine_point(const Params& prm, const void* base
 
 constexpr int kRefT = 1024;
 
-template <bool DEPTH>
+// GCELLS: the cell list of the current label lives in global scratch instead of LDS (frames with more than ~39 000
+// cells, e.g. 3840x2160 at P = 10)
+template <bool DEPTH, bool GCELLS = false>
 __global__ __launch_bounds__(kRefT) void k_refine(Params prm, RefineArgs ra) {
   const int frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int C = prm.C, nh = prm.nh, P = prm.P, n_cell = prm.n;
@@ -87,7 +90,8 @@ __global__ __launch_bounds__(kRefT) void k_refine(Params prm, RefineArgs ra) {
   float* shf = reinterpret_cast<float*>(sh + 32);              // 16 floats: 3 sample points (9), model (4)
   int* grp_first = reinterpret_cast<int*>(shf + 16);           // per cell-row group: first index into lcells  [nv+1]
   int* grp_px = grp_first + prm.nv + 1;                        // cumulative pixel count before the group   [nv+1]
-  int* lcells = grp_px + prm.nv + 1;                           // [C] cells of the current label, ascending
+  int* lcells = GCELLS ? ra.g_cells + static_cast<size_t>(blockIdx.x) * prm.C  // [C] cells of the current label, ascending
+                       : grp_px + prm.nv + 1;
   const int32_t* cl = ra.cell_labels + static_cast<size_t>(frame) * C;
   int32_t* labels = ra.labels + static_cast<size_t>(frame) * prm.N;
   const void* base = DEPTH ? static_cast<const void*>(static_cast<const uint16_t*>(ra.input) + static_cast<size_t>(frame) * prm.N)

@@ -533,10 +533,26 @@ def test_debug_dumps(D, oracle, tum_depth, tmp_path):
             assert np.array_equal(d3.ravel(), labels) and not (tmp_path / str(refine) / "dbg_4_refined_labels.csv").exists()
 
 
-def test_ransac_refinement_parity(D, oracle, tum_depth, icl_depth):
+@pytest.mark.parametrize("env", [None, "DPX_REFINE_GCELLS"])
+def test_ransac_refinement_parity(D, oracle, tum_depth, icl_depth, env):
     """refineLabels (plane_extractor.cpp:472-509) on the device: same label maps as the oracle (which uses
     std::mt19937 / std::uniform_int_distribution directly), through the depth and the cloud entry points, plus the
-    reference's own invariant (cpp/tests/test_refinement.cpp:43-75)."""
+    reference's own invariant (cpp/tests/test_refinement.cpp:43-75).  DPX_REFINE_GCELLS: the label's cell list in
+    global scratch, as for frames too large for LDS."""
+    if env:
+        os.environ[env] = "1"
+    try:
+        _refinement_cases(D, oracle, tum_depth, icl_depth)
+        if env is None:  # a frame whose cell list (46 215 cells) does not fit LDS
+            depth = synth.synth_depth(819, 2766, seed=736, scale=5.0)[None]
+            full_compare(D, oracle, depth, synth.intrinsics_for(819, 2766),
+                         oracle.default_config(patch_size=7, ransac_refinement=1, ransac_max_iterations=50))
+    finally:
+        if env:
+            del os.environ[env]
+
+
+def _refinement_cases(D, oracle, tum_depth, icl_depth):
     oracle.set_math("devmath")
     cases = [(tum_depth, synth.TUM_K, synth.TUM_INI), (icl_depth, synth.ICL_K, synth.ICL_INI)]
     for depth, kpath, ini in cases:

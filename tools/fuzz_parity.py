@@ -1,5 +1,5 @@
 """Randomised parity sweep: random image sizes, patch sizes, configurations, input forms and kernel tiers against the
-oracle (labels, cell records, plane records, statistics).  usage: fuzz_parity.py [cases] [seed]"""
+oracle (labels, cell records, plane records, statistics).  usage: fuzz_parity.py [cases] [seed] [share of large frames]"""
 import os, sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
@@ -42,14 +42,17 @@ def fuzz_pipeline(rng, depth, intr, ocfg, xyz):
     del pipe
 
 
+BIG_FRACTION = float(sys.argv[3]) if len(sys.argv) > 3 else 0.1  # share of large frames (up to ~4K-sized grids)
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time()
 fails = 0
 for it in range(cases):
     P = int(rng.choice([4, 8, 10, 10, 10, 6, 5, 7, 12, 16]))
-    big = rng.random() < 0.1
-    nh, nv = int(rng.integers(1, 200 if big else 90)), int(rng.integers(1, 130 if big else 60))
+    big = rng.random() < BIG_FRACTION
+    huge = big and rng.random() < 0.25
+    nh = int(rng.integers(1, 400 if huge else (200 if big else 90)))
+    nv = int(rng.integers(1, 230 if huge else (130 if big else 60)))
     w = nh * P + int(rng.choice([0, 0, 0, 1, 2, 3]))
     h = nv * P + int(rng.choice([0, 0, 1, P - 1]))
     ov = {"patch_size": P}
