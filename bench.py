@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DPX_BENCH_STREAMS", 16)))
     ap.add_argument("--group", type=int, default=int(os.environ.get("DPX_BENCH_GROUP", 8)), help="submissions per region-growing launch")
-    ap.add_argument("--prof-every", type=int, default=8, help="record per-kernel HIP events on every n-th slot")
+    ap.add_argument("--prof-every", type=int, default=16, help="record per-kernel HIP events on every n-th slot")
     ap.add_argument("--roofline-iters", type=int, default=50)
     ap.add_argument("--no-cloud-roofline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="only the stand-alone plane-fit series (for rocprofv3 --stats / --pmc runs)")
