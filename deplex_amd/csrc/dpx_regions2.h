@@ -1,18 +1,23 @@
-// dpx_regions2.h — K4+K5, second generation: one workgroup (DPX_RT threads) per frame.
+// dpx_regions2.h — K3+K4+K5: cell graph, histogram seeding, FIFO region growing, segment fits, plane merging; one
+// workgroup (DPX_RT threads) per frame.
 //
-// Same algorithm and the same bit-exact results as dpx_regions.h (kept as the fallback for frames whose state does
-// not fit LDS); what changes is where the time goes:
-//   * all per-cell state of the sequential phase lives in LDS (flags, queue, queue position, bin-sorted order, and in
-//     the FULL tier also the cell's bin and mse), so a seed iteration never waits on HBM/L2;
-//   * the LDS flag byte of a cell holds its IN-edges (which neighbours may activate it, k_cellgraph bits 8..11), so a
-//     BFS lane needs only the target cell's byte, and duplicate resolution is PULL based: the lane reads the queue
-//     positions of the target's four neighbours and loses to any in-neighbour that sits earlier in the current FIFO
-//     batch — 2 dependent LDS round trips per BFS step instead of ~8 for the claim/re-claim protocol of v1;
-//   * a grown cell leaves the histogram at activation time (LDS atomic), the arg-max runs over a register-resident
-//     list of the non-empty bins, and the seed search compacts the bin's cell list in place as it scans it;
-//   * wave reductions use DPP row shifts/broadcasts (gfx9) instead of ds_bpermute butterflies;
-//   * the parallel phases (state load, float accumulation of the grown segments, f64 segment fits, label writes) use
-//     all four waves; the inherently sequential seed loop runs on wave 0 while the others wait at the barrier.
+// Same algorithm and the same bit-exact results as dpx_regions.h (the first-generation kernel, kept as the fallback
+// for frames beyond every tier here and as a cross-check); what changes is where the time goes:
+//   * the per-cell state of the sequential phase lives in LDS as far as the frame allows (tiers below: flag byte,
+//     queue, queue positions, seed lists, bin), so a grow iteration waits on LDS, not on HBM/L2;
+//   * the LDS flag byte of a cell holds its IN-edges (which neighbours may activate it), so a BFS lane needs only the
+//     target cell's byte, and duplicate resolution is PULL based: the lane reads the queue positions of the target's
+//     four neighbours and loses to any in-neighbour that sits earlier in the current FIFO batch — 2 dependent LDS
+//     round trips per BFS step instead of ~8 for the claim / re-claim protocol of the first generation;
+//   * seed lists are sorted once per frame by (bin, MSE, cell id): the reference's "first minimum-MSE cell of the most
+//     frequent bin" is the first live entry of the bin's list; a grown cell leaves the histogram at activation time
+//     (LDS atomic) and the arg-max runs over a register-resident list of the non-empty bins;
+//   * seeds whose neighbours cannot be activated are committed without a BFS step; in tier 0 large regions grow with
+//     workgroup-wide BFS batches;
+//   * wave reductions use DPP row shifts / broadcasts (gfx9) instead of ds_bpermute butterflies;
+//   * the parallel phases (state load, sort, float accumulation of the grown segments, f64 segment fits, label
+//     writes, adjacency build) use all eight waves; the inherently sequential sequence of grows runs on wave 0 — as a
+//     one-wave launch of its own in the phase-split form.
 // Reference: plane_extractor.cpp:297-453, normals_histogram.cpp:51-72 (see dpx_regions.h for the parity notes).
 #pragma once
 #include <type_traits>
@@ -121,16 +126,17 @@ struct Regions2Extra {
 //
 // PHASE splits the kernel into three launches that hand the workgroup's LDS image over through global memory:
 //   1 = preparation (P0, kRT threads), 2 = seeds + region growing (P1, ONE wave per frame), 3 = the parallel tail
-//   (P2..P6, kRT threads); 0 = everything in one launch.  Why: the sequential phase takes ~85 % of the kernel's time but
+//   (P2..P6, kRT threads); 0 = everything in one launch.  Why: the sequential phase takes ~2/3 of the kernel's time but
 //   uses one wave; in a single launch the other waves of the workgroup sit at a barrier holding ~100 VGPRs each, and with
-//   16 batches in flight the resident region workgroups leave no registers / wave slots for the plane-fit kernel of the
-//   next batches (measured: its marginal cost doubles).  The one-wave launch needs ~1/8 of the registers and slots.
+//   many batches in flight the resident region workgroups leave no registers / wave slots for the plane-fit kernel of
+//   the next batches (measured: its marginal cost doubles).  The one-wave launch needs ~1/8 of the registers and slots
+//   and, in tier 2, 32.6 KB of LDS instead of the preparation's 65 KB.
 #ifndef DPX_REGIONS_PRIO
 #define DPX_REGIONS_PRIO 3
 #endif
 // TIER: where the per-cell state of the sequential phase lives
-//   2 = everything in LDS (13 B/cell), cell graph fused in, seed = scan of the bin's (unsorted) list;
-//   1 = flags, queue, queue positions and the SORTED seed lists in LDS (7 B/cell); bins via the cell-graph words;
+//   2 = everything in LDS (9 B/cell + 8 B per sort slot while preparing), cell graph fused in, seed lists sorted in LDS;
+//   1 = flags, queue, queue positions and the seed lists in LDS (7 B/cell); bins via the cell-graph words;
 //   0 = only the flag byte in LDS; queue, queue positions and sorted seed lists in global memory (L2) with 32-bit
 //       indices — frames up to ~150 000 cells (3840x2160 at P = 10 has 82 944).
 // Tiers 1 and 0 take their seed lists from dpx_binsort.h (rb.order + rx.bin_off).
