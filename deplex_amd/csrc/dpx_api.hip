@@ -242,10 +242,10 @@ void launch_planefit_depth(dpx_handle h, const dpx::Params& prm, const void* d_i
 
 // A batch goes through two host-side stages on one stream:
 //   stage_fit  : plane fit of `batch` frames into the handle's cell records at frame offset `frame_off`
-//   stage_rest : region growing (+ cell graph for the fallback tiers), label expansion (fused into the region kernel's
-//                tail when possible) and the optional refinement for `nsub` sub-batches of `per_sub` frames that were
-//                fitted before — one launch for all of them (dpx_pipeline groups several submissions this way: the GPU
-//                runs only ~6-7 kernels concurrently, so a latency-bound region launch per 64 frames wastes kernel slots).
+//   stage_rest : region growing (+ cell graph and seed-list sort kernels for tiers 1 / 0), label expansion and the
+//                optional refinement for `nsub` sub-batches of `per_sub` frames that were fitted before — one region
+//                launch sequence and one label launch for all of them (dpx_pipeline groups several submissions this
+//                way: a latency-bound region launch per 64 frames costs more than it needs to).
 struct SubBatch {
   const void* d_in;
   int32_t* d_labels;
