@@ -459,13 +459,14 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
               if (i < e) {
                 c = order[i];
                 const int cc = static_cast<int>(c);
-                const int wU = cc - nh > 0 ? cc - nh : 0, wD = cc + nh < C ? cc + nh : C - 1;
-                const int wL = cc > 0 ? cc - 1 : 0, wR = cc + 1 < C ? cc + 1 : C - 1;
+                // (not clamped: the flag bytes are in LDS in every tier, a read outside the grid returns bytes of the
+                // neighbouring arrays and can only make the cell look connected — see below)
+                const int wU = cc - nh, wD = cc + nh, wL = cc - 1, wR = cc + 1;
                 f = flags[cc];
                 const uint32_t fU = flags[wU], fD = flags[wD], fL = flags[wL], fR = flags[wR];
                 alive = (f & F_UNASSIGNED) != 0;
                 // a neighbour that is unassigned and whose in-edge bit for this cell's side is set can be activated from
-                // here; clamped (non-existent) neighbours can only make a cell look connected, never isolated
+                // here; non-existent neighbours can only make a cell look connected, never isolated
                 const uint32_t out = ((fU & (fU >> 3)) | (fD & (fD >> 2)) | (fL & (fL >> 5)) | (fR & (fR >> 4))) & 1u;
                 iso = alive && out == 0u && iso_ok;
               }
@@ -510,8 +511,8 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
             flags[seed] = static_cast<uint8_t>(flags[seed] & ~F_UNASSIGNED);
             atomicSub(&hist[bb], 1);  // hist.removePoint(seed); the seed's bin is bb
           }
-          ++tail;
-          head = gstart;
+          tail = __builtin_amdgcn_readfirstlane(tail + 1);
+          head = __builtin_amdgcn_readfirstlane(gstart);
           in_grow = true;
           st = 0;
           wave_sync();
@@ -533,13 +534,15 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
             const bool inrange = active && (vraw >= 0) && (vraw < C);
             const int v = vraw < 0 ? 0 : (vraw >= C ? C - 1 : vraw);
             const uint32_t fv = flags[v];
-            // positions of v's four neighbours in the queue (kNoPos = never activated); out-of-grid neighbours are
-            // clamped to a valid address and are harmless because v's in-edge bit for them is 0 (k_cellgraph)
-            const int wU = v - nh > 0 ? v - nh : 0, wD = v + nh < C ? v + nh : C - 1;
-            const int wL = v - 1 > 0 ? v - 1 : 0, wR = v + 1 < C ? v + 1 : C - 1;
+            // positions of v's four neighbours in the queue.  In the LDS tiers the reads are not clamped: an index outside
+            // the grid lands in the neighbouring LDS arrays, and whatever it returns is masked by v's in-edge bit for that
+            // (non-existent) neighbour being 0.  Tier 0 reads global memory and clamps.
+            const int wU = GST ? (v - nh > 0 ? v - nh : 0) : v - nh, wD = GST ? (v + nh < C ? v + nh : C - 1) : v + nh;
+            const int wL = GST ? (v - 1 > 0 ? v - 1 : 0) : v - 1, wR = GST ? (v + 1 < C ? v + 1 : C - 1) : v + 1;
             const uint32_t qU = qpos[wU], qD = qpos[wD], qL = qpos[wL], qR = qpos[wR];
             // v's bin, needed only if v is activated, is fetched with the reads above instead of after the decision
-            const int bin_v = (FULL ? static_cast<int>(binof[v]) : static_cast<int>(meta[v] >> META_BIN_SHIFT)) - 1;
+            int bin_v = (FULL ? static_cast<int>(binof[v]) : static_cast<int>(meta[v] >> META_BIN_SHIFT)) - 1;
+            asm volatile("" : "+v"(bin_v));  // keep the load up here with the others (it would be sunk into the branch)
             // bit k set: v's neighbour k sits EARLIER in this FIFO batch (queue position in [batch head, batch head + slot))
             const uint32_t earlier = (((qU - uh) < us) ? 1u : 0u) | (((qD - uh) < us) ? 2u : 0u) |
                                      (((qL - uh) < us) ? 4u : 0u) | (((qR - uh) < us) ? 8u : 0u);
@@ -557,8 +560,9 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
               flags[v] = static_cast<uint8_t>(fv & ~F_UNASSIGNED);
               if (bin_v >= 0 && bin_v < nb) atomicSub(&hist[bin_v], 1);  // hist.removePoint at activation time
             }
-            tail += __popcll(mask);
-            head += nslots;
+            // head and tail are wave-uniform: keep them in scalar registers (the compiler cannot prove it)
+            tail = __builtin_amdgcn_readfirstlane(tail + static_cast<int>(__popcll(mask)));
+            head = __builtin_amdgcn_readfirstlane(head + nslots);
             if constexpr (GST) {
               wave_sync();  // queue / queue positions in global memory: the next step's loads must see these stores
             } else {
@@ -598,13 +602,15 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
             const bool inrange = active && (vraw >= 0) && (vraw < C);
             const int v = vraw < 0 ? 0 : (vraw >= C ? C - 1 : vraw);
             const uint32_t fv = flags[v];
-            // positions of v's four neighbours in the queue (kNoPos = never activated); out-of-grid neighbours are
-            // clamped to a valid address and are harmless because v's in-edge bit for them is 0 (k_cellgraph)
-            const int wU = v - nh > 0 ? v - nh : 0, wD = v + nh < C ? v + nh : C - 1;
-            const int wL = v - 1 > 0 ? v - 1 : 0, wR = v + 1 < C ? v + 1 : C - 1;
+            // positions of v's four neighbours in the queue.  In the LDS tiers the reads are not clamped: an index outside
+            // the grid lands in the neighbouring LDS arrays, and whatever it returns is masked by v's in-edge bit for that
+            // (non-existent) neighbour being 0.  Tier 0 reads global memory and clamps.
+            const int wU = GST ? (v - nh > 0 ? v - nh : 0) : v - nh, wD = GST ? (v + nh < C ? v + nh : C - 1) : v + nh;
+            const int wL = GST ? (v - 1 > 0 ? v - 1 : 0) : v - 1, wR = GST ? (v + 1 < C ? v + 1 : C - 1) : v + 1;
             const uint32_t qU = qpos[wU], qD = qpos[wD], qL = qpos[wL], qR = qpos[wR];
             // v's bin, needed only if v is activated, is fetched with the reads above instead of after the decision
-            const int bin_v = (FULL ? static_cast<int>(binof[v]) : static_cast<int>(meta[v] >> META_BIN_SHIFT)) - 1;
+            int bin_v = (FULL ? static_cast<int>(binof[v]) : static_cast<int>(meta[v] >> META_BIN_SHIFT)) - 1;
+            asm volatile("" : "+v"(bin_v));  // keep the load up here with the others (it would be sunk into the branch)
             // bit k set: v's neighbour k sits EARLIER in this FIFO batch (queue position in [batch head, batch head + slot))
             const uint32_t earlier = (((qU - uh) < us) ? 1u : 0u) | (((qD - uh) < us) ? 2u : 0u) |
                                      (((qL - uh) < us) ? 4u : 0u) | (((qR - uh) < us) ? 8u : 0u);
