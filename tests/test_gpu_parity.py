@@ -230,6 +230,19 @@ def test_ragged_and_tiny_images(D, oracle):
     for (h, w) in [(250, 330), (37, 53), (10, 10), (9, 200)]:
         depth = synth.synth_batch(2, h, w, seed0=1)
         full_compare(D, oracle, depth, synth.intrinsics_for(h, w), oracle.default_config())
+    # one-row / one-column cell grids with a tiny histogram: neighbour indices of the BFS and of the seed scan leave the
+    # grid on every step (they are not clamped in the LDS tiers)
+    for (h, w) in [(10, 4000), (4000, 10), (20, 3000)]:
+        for env in (None, "DPX_REGIONS_LEAN", "DPX_REGIONS_GSTATE"):
+            if env:
+                os.environ[env] = "1"
+            try:
+                depth = synth.synth_batch(2, h, w, seed0=9)
+                full_compare(D, oracle, depth, synth.intrinsics_for(h, w),
+                             oracle.default_config(histogram_bins_per_coord=3, min_region_growing_cells_activated=2))
+            finally:
+                if env:
+                    del os.environ[env]
 
 
 @pytest.mark.parametrize("env", ["DPX_FORCE_GLOBAL_STATE", "DPX_REGIONS_V1", "DPX_REGIONS_LEAN", "DPX_REGIONS_GSTATE", "DPX_NO_FASTDIV", "DPX_PLANEFIT_V1", "DPX_LABELS_V1", "DPX_REGIONS_NOSPLIT", "DPX_FUSED_LABELS"])
