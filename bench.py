@@ -28,22 +28,29 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+# plane-fit kernel (depth): VALU instructions per pixel / per cell in the ISA and the chip's
+# measured VALU rates in T lane-operations/s (tools/ubench/pk.hip on MI355X: dependent v_mul->v_add pairs at >= 2 waves
+# per SIMD; v_fma_f32)
+VALU_PER_PIXEL, VALU_PER_CELL = 23.3, 1070
+VALU_PEAK_MULADD_TOPS, VALU_PEAK_FMA_TOPS = 62.7, 39.6
 
 
 def dist_env():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-def make_workload(name: str, batch: int, rank: int):
+def make_workload(name: str, batch: int, rank: int, part: int = 0, parts: int = 1):
+    """Input batch number `part` of rank `rank` (every (rank, part) pair gets its own seeds)."""
     import synth
+    seed0 = (rank * parts + part) * batch
     if name == "tum_stream":
         K = synth.read_K(synth.TUM_K)
-        depth = synth.tum_stream(batch, seed0=rank * batch)
+        depth = synth.tum_stream(batch, seed0=seed0)
         intr = tuple(float(v) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2]))
         return depth, intr, f"TUM fr3 640x480 depth stream (reference frame + seeded variants), batch={batch}"
     if name.startswith("synth"):
         w, h = {"synth640": (640, 480), "synth1280": (1280, 960), "synth4k": (3840, 2160)}[name]
-        depth = synth.synth_batch(batch, h, w, seed0=rank * batch)
+        depth = synth.synth_batch(batch, h, w, seed0=seed0)
         return depth, synth.intrinsics_for(h, w), f"synthetic {w}x{h} piecewise-planar depth, batch={batch}"
     raise SystemExit(f"unknown workload {name}")
 
@@ -102,9 +109,14 @@ def main():
                     help="depth: u16 frames, back-projection fused (the metric); cloud: organised float32 clouds, the reference API's input form")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-frames", type=int, default=4)
+    ap.add_argument("--inputs", type=int, default=8,
+                    help="distinct input batches the steps rotate over (8 x 39 MB of depth frames exceed the 256 MB Infinity Cache)")
     args = ap.parse_args()
 
     rank, local_rank, world = dist_env()
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks with "
+                         f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...")
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -122,13 +134,21 @@ def main():
             dist.init_process_group(backend)
     import deplex_amd as D
 
-    depth, intr, wl_desc = make_workload(args.workload, args.batch, rank)
+    S = max(1, args.streams)  # groups in flight (pipeline slots), one stream each
+    G = max(1, min(8, args.group))
+    # The steps rotate over R distinct input batches (R divides the S*G output buffers, so buffer k always holds the
+    # result of input k % R): together larger than the 256 MB Infinity Cache, i.e. the frames stream from HBM.
+    R = max(1, min(args.inputs, S * G))
+    while (S * G) % R:
+        R -= 1
+    parts = [make_workload(args.workload, args.batch, rank, r, R) for r in range(R)]
+    depths = [p[0] for p in parts]
+    depth, intr, wl_desc = parts[0]
     B, H, W = depth.shape
     N = H * W
     dev = torch.device("cuda", local_rank)
-    d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
-    S = max(1, args.streams)  # batches in flight (pipeline slots), one stream each
-    G = max(1, min(8, args.group))
+    d_depths = [torch.from_numpy(d.view(np.int16)).to(dev) for d in depths]
+    d_depth = d_depths[0]
     d_labels = torch.empty((S * G, B, N), dtype=torch.int32, device=dev)
     pipe = D.Pipeline(H, W, D.Config(), batch=B, slots=S, group=args.group, device=local_rank)
     exs = [pipe.slot(k) for k in range(S)]
@@ -140,16 +160,16 @@ def main():
     for k in prof_slots:
         exs[k].set_profiling(True)
 
-    d_cloud = None
+    d_clouds = None
     if args.input == "cloud":
         from oracle import oracle as O  # back-projection of the bench frames (input preparation, outside any timed region)
-        d_cloud = torch.from_numpy(np.stack([O.backproject(f, *[np.float32(v) for v in intr]) for f in depth])).to(dev)
+        d_clouds = [torch.from_numpy(np.stack([O.backproject(f, *[np.float32(v) for v in intr]) for f in d])).to(dev) for d in depths]
 
     def step(i):
-        if d_cloud is not None:
-            pipe.submit_pcd(d_cloud.data_ptr(), B, d_labels[i % (S * G)].data_ptr())
+        if d_clouds is not None:
+            pipe.submit_pcd(d_clouds[i % R].data_ptr(), B, d_labels[i % (S * G)].data_ptr())
         else:
-            pipe.submit_depth(d_depth.data_ptr(), B, *intr, d_labels[i % (S * G)].data_ptr())
+            pipe.submit_depth(d_depths[i % R].data_ptr(), B, *intr, d_labels[i % (S * G)].data_ptr())
 
     def sync():
         pipe.sync()
@@ -159,20 +179,26 @@ def main():
         if world > 1:
             dist.barrier()
 
-    if args.roofline_only:
+    # The plane-fit launch the pipeline issues: ONE launch over the G submissions of a group, each with its own input
+    # buffer (G * B frames; G distinct buffers of the rotation, so the launch reads G x 39 MB from HBM).
+    def planefit_series(cloud: bool, iters: int):
         rstream = torch.cuda.Stream(device=dev)
-        cloud = args.roofline_input == "cloud"
         if cloud:
             from oracle import oracle as O  # back-projection of the bench frames (input preparation only)
-            xyz = np.stack([O.backproject(f, *[np.float32(v) for v in intr]) for f in depth])
-            d_in = torch.from_numpy(xyz).to(dev)
+            bufs = [torch.from_numpy(np.stack([O.backproject(f, *[np.float32(v) for v in intr]) for f in depths[j % R]])).to(dev)
+                    for j in range(min(G, R))]
         else:
-            d_in = d_depth
-        exs[0].time_planefit(d_in.data_ptr(), int(cloud), B, *intr, 5, rstream.cuda_stream)
-        ms = exs[0].time_planefit(d_in.data_ptr(), int(cloud), B, *intr, args.roofline_iters, rstream.cuda_stream)
-        by = exs[0].planefit_bytes(int(cloud), B)
+            bufs = d_depths
+        ptrs = [bufs[j % len(bufs)].data_ptr() for j in range(G)]
+        exs[0].time_planefit_group(ptrs, int(cloud), B, *intr, 3, rstream.cuda_stream)
+        ms = exs[0].time_planefit_group(ptrs, int(cloud), B, *intr, iters, rstream.cuda_stream)
+        return ms, exs[0].planefit_bytes(int(cloud), G * B)
+
+    if args.roofline_only:
+        cloud = args.roofline_input == "cloud"
+        ms, by = planefit_series(cloud, args.roofline_iters)
         print(json.dumps({"roofline_only": True, "kernel": "k_planefit_cloud_lds" if cloud else "k_planefit_depth", "batch": B,
-                          "workload": args.workload, "avg_launch_ms": round(ms, 4), "bytes_per_launch": by,
+                          "frames_per_launch": G * B, "workload": args.workload, "avg_launch_ms": round(ms, 4), "bytes_per_launch": by,
                           "achieved_GBps": round(by / (ms * 1e-3) / 1e9, 1), "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}))
         return
     elapsed = timed_region(step, sync, barrier, args.steps, args.warmup)
@@ -181,28 +207,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-kernel durations measured with HIP events on the launch streams during the timed steps (sampled slots).  With
-    # S batches in flight these include the time a launch spends sharing the GPU with the other batches' kernels.
+    # per-kernel durations measured with HIP events on the launch streams during the timed steps (sampled slots): one
+    # plane-fit / region / label launch sequence per GROUP of G submissions.  With S groups in flight these include the
+    # time a launch spends sharing the GPU with the other groups' kernels.
     kms = {k: 0.0 for k in ("planefit", "cellgraph", "regions", "labels")}
-    used = [k for k in prof_slots if k < args.steps + args.warmup]
+    used = [k for k in prof_slots if k * G < args.steps + args.warmup]
     for k in used:
         for name, v in exs[k].kernel_ms().items():
             kms[name] += v / len(used)
-    # roofline of the plane-fit kernel: the same launch (same batch, same buffers) issued back to back on one stream
-    # right after the timed region, bracketed by HIP events on that stream
+    # roofline of the plane-fit kernel: the same group launch issued back to back on one stream right after the timed
+    # region, bracketed by HIP events on that stream
     sync()
-    rstream = torch.cuda.Stream(device=dev)
-    exs[0].time_planefit(d_depth.data_ptr(), 0, B, *intr, 5, rstream.cuda_stream)
-    pf_alone_ms = exs[0].time_planefit(d_depth.data_ptr(), 0, B, *intr, args.roofline_iters, rstream.cuda_stream)
+    pf_alone_ms, pf_bytes = planefit_series(False, args.roofline_iters)
     # the same kernel stage fed with the reference API's own input (organised float32 cloud, 12 B/point)
-    cloud_ms = None
+    cloud_ms = cloud_bytes = None
     if rank == 0 and not args.no_cloud_roofline:
-        from oracle import oracle as O  # back-projection of the bench frames (outside any timed region)
-        xyz = np.stack([O.backproject(f, *[np.float32(v) for v in intr]) for f in depth])
-        d_xyz = torch.from_numpy(xyz).to(dev)
-        exs[0].time_planefit(d_xyz.data_ptr(), 1, B, *intr, 5, rstream.cuda_stream)
-        cloud_ms = exs[0].time_planefit(d_xyz.data_ptr(), 1, B, *intr, args.roofline_iters, rstream.cuda_stream)
-        del d_xyz
+        cloud_ms, cloud_bytes = planefit_series(True, max(4, args.roofline_iters // 4))
 
     # parity spot check against the oracle (outside the timed region; the oracle is only the checker)
     parity = "unchecked"
@@ -210,22 +230,27 @@ def main():
         from oracle import oracle as O
         O.set_math("devmath")
         nchk = min(args.parity_frames, B)
-        got = d_labels[(args.steps - 1) % (S * G), :nchk].cpu().numpy()
-        ref = O.process_depth_batch(O.default_config(), depth[:nchk], *intr, threads=min(nchk, os.cpu_count() or 1))
-        if not np.array_equal(got, ref):
-            raise SystemExit("bench: HIP label maps differ from the oracle — refusing to report a number")
-        # every step processed the same frames: all output buffers of the in-flight window must hold the same bits
-        # (catches a slot being reused before its previous submission finished)
+        last = args.steps - 1
+        # the last step and the first inputs of the rotation (output buffer k holds the result of input k % R)
         nbuf = min(max(args.steps, args.warmup), S * G)  # (warm-up and timed steps both index the buffers from 0)
-        same = all(bool(torch.equal(d_labels[k], d_labels[0])) for k in range(1, nbuf))
+        check = sorted({last % (S * G)} | {k for k in range(min(R, nbuf))})
+        ncheck = 0
+        for k in check[:3] if len(check) > 3 else check:
+            got = d_labels[k, :nchk].cpu().numpy()
+            ref = O.process_depth_batch(O.default_config(), depths[k % R][:nchk], *intr, threads=min(nchk, os.cpu_count() or 1))
+            if not np.array_equal(got, ref):
+                raise SystemExit("bench: HIP label maps differ from the oracle — refusing to report a number")
+            ncheck += nchk
+        # all output buffers of the in-flight window that hold the same input must hold the same bits (catches a slot
+        # being reused before its previous submission finished)
+        same = all(bool(torch.equal(d_labels[k], d_labels[k % R])) for k in range(R, nbuf))
         if not same:
             raise SystemExit("bench: output buffers of different in-flight submissions differ — refusing to report a number")
-        parity = f"bit-exact label maps vs oracle on {nchk} frames; {nbuf} in-flight output buffers identical"
+        parity = f"bit-exact label maps vs oracle on {ncheck} frames; {nbuf} in-flight output buffers consistent over {R} rotating inputs"
 
     if rank == 0:
         total_frames = B * args.steps * world
         fps = total_frames / elapsed
-        pf_bytes = exs[0].planefit_bytes(0, B)
         pf_ms = pf_alone_ms
         achieved = pf_bytes / (pf_ms * 1e-3) / 1e9 if pf_ms > 0 else 0.0
         in_pipe = pf_bytes / (kms["planefit"] * 1e-3) / 1e9 if kms["planefit"] > 0 else 0.0
@@ -234,44 +259,47 @@ def main():
         if tfile.exists():
             try:
                 tj = json.loads(tfile.read_text())
-                if tj.get("batch") == B and tj.get("workload") == args.workload:
+                if tj.get("frames_per_launch") == G * B and tj.get("workload") == args.workload:
                     traffic = tj.get("hbm_bytes_per_launch")
-                cloud_traffic = tj.get("cloud", {}).get("hbm_bytes_per_launch")
+                    cloud_traffic = tj.get("cloud", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # lane-operations of the exact arithmetic in the kernel's ISA: VALU_PER_PIXEL per pixel
+        # + VALU_PER_CELL per cell for the f64 plane fit; the chip's measured rates for that mix are in tools/ubench/pk.hip
+        lane_ops = int(G * B * (VALU_PER_PIXEL * N + VALU_PER_CELL * (W // 10) * (H // 10)))
         out = {
             "metric": ("depth frames/sec (640x480)" if (W, H) == (640, 480) else f"depth frames/sec ({W}x{H})") +
                       (" [organised-cloud input]" if args.input == "cloud" else ""),
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl_desc, "patch_size": 10, "batch_per_gpu": B, "groups_in_flight": S, "batches_per_region_launch": G,
+            "config": {"workload": wl_desc, "patch_size": 10, "batch_per_gpu": B, "groups_in_flight": S, "batches_per_launch": G,
+                       "distinct_input_batches": R, "input_bytes_in_rotation": int(R * B * N * (12 if args.input == "cloud" else 2)),
                        "streams": f"{S} (one per group in flight), GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}",
                        "arithmetic": "f32 moments (reference order), f64 3x3 eigen, int32 labels",
                        "parallelism": f"frame-shard x{world}, no collectives"},
             "parity": parity,
             "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
-            "roofline": {"kernel": "k_planefit (depth -> per-cell moments + eigen plane fit)", "bound": "hbm",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": "k_planefit_depth (depth -> per-cell moments + eigen plane fit), one launch per group of "
+                                   f"{G} submissions = {G * B} frames",
+                         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "bytes_per_launch": pf_bytes, "avg_launch_ms": round(pf_ms, 4),
-                         # the kernel's actual bound: VALU issue.  23.3 instructions per pixel in the
-                         # ISA of the exact moment arithmetic + ~1070 per 64-cell wave for the f64 plane fit, against one
-                         # wave-instruction per 4 cycles per SIMD (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz)
-                         "valu": {"lane_ops_per_launch": int(B * (23.3 * N + 1070 * (W // 10) * (H // 10))),
-                                  "achieved_Tops": round(B * (23.3 * N + 1070 * (W // 10) * (H // 10)) / (pf_ms * 1e-3) / 1e12, 2),
-                                  "issue_peak_Tops": 39.3,
-                                  "frac": round(B * (23.3 * N + 1070 * (W // 10) * (H // 10)) / (pf_ms * 1e-3) / 39.3e12, 3)},
-                         "measured": f"{args.roofline_iters} launches back to back on one stream after the timed region, HIP events on that stream",
+                         "valu": {"lane_ops_per_launch": lane_ops,
+                                  "achieved_Tops": round(lane_ops / (pf_ms * 1e-3) / 1e12, 2),
+                                  "measured_peak_Tops": {"mul_add_mix": VALU_PEAK_MULADD_TOPS, "fma": VALU_PEAK_FMA_TOPS},
+                                  "frac_of_mul_add_peak": round(lane_ops / (pf_ms * 1e-3) / (VALU_PEAK_MULADD_TOPS * 1e12), 3)},
+                         "measured": f"{args.roofline_iters} launches back to back on one stream after the timed region, HIP events on that stream; "
+                                     f"{G} distinct input buffers per launch",
                          "in_pipeline": {"avg_launch_ms": round(kms["planefit"], 4), "achieved": round(in_pipe, 1),
-                                         "note": f"HIP events around the launches of the timed steps with {S} groups of {G} batches in flight (includes queueing behind / sharing with the other batches' kernels)"}},
+                                         "note": f"HIP events around the launches of the timed steps with {S} groups of {G} batches in flight (includes queueing behind / sharing with the other groups' kernels)"}},
         }
         if cloud_ms:
-            cb = exs[0].planefit_bytes(1, B)
-            out["roofline_cloud_input"] = {"kernel": "k_planefit_cloud_lds (organised xyz cloud -> per-cell moments + eigen plane fit)",
-                                           "bound": "hbm", "achieved": round(cb / (cloud_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                                           "unit": "GB/s", "frac": round(cb / (cloud_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                           "traffic": cloud_traffic, "bytes_per_launch": cb, "avg_launch_ms": round(cloud_ms, 4)}
+            out["roofline_cloud_input"] = {"kernel": "k_planefit_cloud_lds (organised xyz cloud -> per-cell moments + eigen plane fit), "
+                                                     f"{G} launches of {B} frames",
+                                           "bound": "hbm", "achieved": round(cloud_bytes / (cloud_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                           "unit": "GB/s", "frac": round(cloud_bytes / (cloud_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                           "traffic": cloud_traffic, "bytes_per_launch": cloud_bytes, "avg_launch_ms": round(cloud_ms, 4)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(depth, intr, min(16, os.cpu_count() or 1))  # the box's CPU share for one GPU
         print(json.dumps(out), flush=True)

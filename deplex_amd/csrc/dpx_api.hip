@@ -87,15 +87,17 @@ struct dpx_handle_s {
   size_t d_in_bytes = 0;
   int32_t* d_labels = nullptr;
   size_t d_labels_bytes = 0;
-  // exact-division-by-reciprocal verification cache (dpx_planefit_fast.h)
-  bool fd_valid = false, fd_ok = false;
-  float fd_fx = 0, fd_fy = 0, fd_cx = 0, fd_cy = 0, fd_rx = 0, fd_ry = 0;
+  // exact-division-by-reciprocal verification cache (dpx_planefit_fast.h): the last few intrinsics tuples seen
+  struct FdEntry {
+    float fx, fy, cx, cy, rx, ry;
+    bool ok;
+  };
+  std::vector<FdEntry> fd_cache;  // most recently used first
   unsigned int* d_mismatch = nullptr;
   // profiling: a ring of event sets, one per process call
   bool profiling = false;
   static constexpr int kProfSlots = 128;
   hipEvent_t ev[kProfSlots][7] = {};  // fit start/end, graph start, graph end = regions start, regions end, labels start/end
-  float last_intr[4] = {1.f, 1.f, 0.f, 0.f};  // intrinsics of the last plane fit (the refinement re-projects with them)
   bool ev_created = false;
   long long prof_calls = 0;
   int last_batch = 0;
@@ -148,45 +150,50 @@ bool fast_shape(const dpx::Params& prm) {
 }
 
 // Verifies (once per intrinsics tuple) that the reciprocal-based division of the fast plane-fit kernel returns the
-// IEEE quotient for every numerator this image geometry can produce.  Synchronises on first use.
-int prepare_intrinsics(dpx_handle h, float fx, float fy, float cx, float cy) {
-  if (h->fd_valid && h->fd_fx == fx && h->fd_fy == fy && h->fd_cx == cx && h->fd_cy == cy) return DPX_OK;
-  h->fd_valid = false;
-  h->fd_ok = false;
-  h->fd_rx = 1.0f / fx;
-  h->fd_ry = 1.0f / fy;
-  if (fast_shape(h->prm) && std::isfinite(h->fd_rx) && std::isfinite(h->fd_ry) && !std::getenv("DPX_NO_FASTDIV")) {
+// IEEE quotient for every numerator this image geometry can produce.  Synchronises the first time a tuple is seen;
+// the last kFdCache tuples are remembered (a stream may alternate between a few cameras).
+constexpr size_t kFdCache = 16;
+int prepare_intrinsics(dpx_handle h, float fx, float fy, float cx, float cy, dpx_handle_s::FdEntry* out) {
+  for (size_t i = 0; i < h->fd_cache.size(); ++i) {
+    const auto& e = h->fd_cache[i];
+    if (e.fx == fx && e.fy == fy && e.cx == cx && e.cy == cy) {
+      if (i != 0) std::rotate(h->fd_cache.begin(), h->fd_cache.begin() + i, h->fd_cache.begin() + i + 1);
+      if (out) *out = h->fd_cache[0];
+      return DPX_OK;
+    }
+  }
+  dpx_handle_s::FdEntry e{fx, fy, cx, cy, 1.0f / fx, 1.0f / fy, false};
+  if (fast_shape(h->prm) && std::isfinite(e.rx) && std::isfinite(e.ry) && !std::getenv("DPX_NO_FASTDIV")) {
     if (!h->d_mismatch) DPX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_mismatch), sizeof(unsigned int)));
     DPX_HIP(hipMemsetAsync(h->d_mismatch, 0, sizeof(unsigned int), h->stream));
     const long long tx = static_cast<long long>(h->W) * 65536, ty = static_cast<long long>(h->H) * 65536;
-    hipLaunchKernelGGL(dpx::k_verify_fastdiv, dim3(static_cast<unsigned>((tx + 255) / 256)), dim3(256), 0, h->stream, h->W, cx, fx, h->fd_rx, h->d_mismatch);
-    hipLaunchKernelGGL(dpx::k_verify_fastdiv, dim3(static_cast<unsigned>((ty + 255) / 256)), dim3(256), 0, h->stream, h->H, cy, fy, h->fd_ry, h->d_mismatch);
+    hipLaunchKernelGGL(dpx::k_verify_fastdiv, dim3(static_cast<unsigned>((tx + 255) / 256)), dim3(256), 0, h->stream, h->W, cx, fx, e.rx, h->d_mismatch);
+    hipLaunchKernelGGL(dpx::k_verify_fastdiv, dim3(static_cast<unsigned>((ty + 255) / 256)), dim3(256), 0, h->stream, h->H, cy, fy, e.ry, h->d_mismatch);
     unsigned int mism = 1;
     DPX_HIP(hipMemcpyAsync(&mism, h->d_mismatch, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
     DPX_HIP(hipStreamSynchronize(h->stream));
-    h->fd_ok = (mism == 0);
+    e.ok = (mism == 0);
   }
-  h->fd_fx = fx; h->fd_fy = fy; h->fd_cx = cx; h->fd_cy = cy;
-  h->fd_valid = true;
+  if (h->fd_cache.size() >= kFdCache) h->fd_cache.pop_back();
+  h->fd_cache.insert(h->fd_cache.begin(), e);
+  if (out) *out = e;
   return DPX_OK;
 }
 
 template <int P>
-void launch_planefit_fast(const dpx::Params& prm, const void* d_in, dpx_cell* d_cells, hipStream_t s, bool fastdiv, float rx, float ry) {
+void launch_planefit_fast(const dpx::Params& prm, const dpx::PfGroup& grp, dpx_cell* d_cells, hipStream_t s, bool fastdiv) {
   const long long waves = static_cast<long long>(prm.batch) * prm.nv * ((prm.nh + 63) / 64);
   const unsigned blocks = static_cast<unsigned>((waves + 3) / 4);
   static const int diag = std::getenv("DPX_PF_DIAG") ? std::atoi(std::getenv("DPX_PF_DIAG")) : 0;
   if (P == 10 && diag == 1)
-    hipLaunchKernelGGL((dpx::k_planefit_depth<10, true, 1>), dim3(blocks), dim3(256), 0, s, prm, static_cast<const uint16_t*>(d_in), d_cells, rx, ry);
+    hipLaunchKernelGGL((dpx::k_planefit_depth<10, true, 1>), dim3(blocks), dim3(256), 0, s, prm, grp, d_cells);
   else if (P == 10 && diag == 2)
-    hipLaunchKernelGGL((dpx::k_planefit_depth<10, true, 2>), dim3(blocks), dim3(256), 0, s, prm, static_cast<const uint16_t*>(d_in), d_cells, rx, ry);
+    hipLaunchKernelGGL((dpx::k_planefit_depth<10, true, 2>), dim3(blocks), dim3(256), 0, s, prm, grp, d_cells);
   else if (fastdiv)
-    hipLaunchKernelGGL((dpx::k_planefit_depth<P, true>), dim3(blocks), dim3(256), 0, s, prm, static_cast<const uint16_t*>(d_in), d_cells, rx, ry);
+    hipLaunchKernelGGL((dpx::k_planefit_depth<P, true>), dim3(blocks), dim3(256), 0, s, prm, grp, d_cells);
   else
-    hipLaunchKernelGGL((dpx::k_planefit_depth<P, false>), dim3(blocks), dim3(256), 0, s, prm, static_cast<const uint16_t*>(d_in), d_cells, rx, ry);
+    hipLaunchKernelGGL((dpx::k_planefit_depth<P, false>), dim3(blocks), dim3(256), 0, s, prm, grp, d_cells);
 }
-
-void launch_planefit_depth(dpx_handle h, const dpx::Params& prm, const void* d_in, dpx_cell* d_cells, hipStream_t s);
 
 template <bool DEPTH>
 void launch_planefit(const dpx::Params& prm, const void* d_in, dpx_cell* d_cells, hipStream_t s) {
@@ -227,28 +234,35 @@ void launch_planefit_cloud(dpx_handle h, const dpx::Params& prm, const void* d_i
   launch_planefit<false>(prm, d_in, d_cells, s);
 }
 
-void launch_planefit_depth(dpx_handle h, const dpx::Params& prm, const void* d_in, dpx_cell* d_cells, hipStream_t s) {
+// true: this frame geometry runs the tuned depth kernel (k_planefit_depth), which takes a whole group per launch
+bool depth_fast_path(const dpx::Params& prm) {
   const char* v1 = std::getenv("DPX_PLANEFIT_V1");
-  if (fast_shape(prm) && !(v1 && v1[0] == '1')) {
-    switch (prm.P) {
-      case 4: launch_planefit_fast<4>(prm, d_in, d_cells, s, h->fd_ok, h->fd_rx, h->fd_ry); return;
-      case 8: launch_planefit_fast<8>(prm, d_in, d_cells, s, h->fd_ok, h->fd_rx, h->fd_ry); return;
-      case 10: launch_planefit_fast<10>(prm, d_in, d_cells, s, h->fd_ok, h->fd_rx, h->fd_ry); return;
-      default: break;
-    }
-  }
-  launch_planefit<true>(prm, d_in, d_cells, s);
+  return fast_shape(prm) && !(v1 && v1[0] == '1');
 }
 
-// A batch goes through two host-side stages on one stream:
-//   stage_fit  : plane fit of `batch` frames into the handle's cell records at frame offset `frame_off`
+// prm.batch frames = the group's submissions back to back; every submission verified for the same division flavour
+void launch_planefit_depth_group(const dpx::Params& prm, const dpx::PfGroup& grp, dpx_cell* d_cells, hipStream_t s, bool fastdiv) {
+  switch (prm.P) {
+    case 4: launch_planefit_fast<4>(prm, grp, d_cells, s, fastdiv); return;
+    case 8: launch_planefit_fast<8>(prm, grp, d_cells, s, fastdiv); return;
+    default: launch_planefit_fast<10>(prm, grp, d_cells, s, fastdiv); return;
+  }
+}
+
+// A group of `nsub` sub-batches of `per_sub` frames each (one submission of a dpx_pipeline group, or the whole batch of
+// a single call) goes through two host-side stages on one stream:
+//   stage_fit  : plane fit of all sub-batches into the handle's cell records (frame-major, sub-batch after sub-batch)
+//                — one launch for the whole group on the tuned depth path
 //   stage_rest : region growing (+ cell graph and seed-list sort kernels for tiers 1 / 0), label expansion and the
-//                optional refinement for `nsub` sub-batches of `per_sub` frames that were fitted before — one region
-//                launch sequence and one label launch for all of them (dpx_pipeline groups several submissions this
-//                way: a latency-bound region launch per 64 frames costs more than it needs to).
+//                optional refinement — one region launch sequence and one label launch for all sub-batches
+// (a launch per 64 frames leaves the chip under-filled at its start and end and, for the latency-bound region kernels,
+// costs more than it needs to).
 struct SubBatch {
   const void* d_in;
   int32_t* d_labels;
+  float fx, fy, cx, cy;  // intrinsics of this sub-batch (plane fit; the refinement re-projects its depth with them)
+  float rx, ry;          // verified reciprocals of fx, fy
+  bool fd_ok;            // the reciprocal division is exact for this geometry (else IEEE division)
 };
 
 // seed lists of the sorted region tiers (dpx_binsort.h): keys -> bitonic network -> per-bin cell lists
@@ -269,32 +283,66 @@ void launch_binsort(dpx_handle h, const dpx::Params& prm, hipStream_t s) {
   hipLaunchKernelGGL(dpx::k_sort_lists, dim3(g256), dim3(256), 0, s, prm, h->d_sort_keys, Cpad, h->d_order, h->d_bin_off);
 }
 
-int stage_fit(dpx_handle h, const void* d_in, bool depth, int batch, float fx, float fy, float cx, float cy, int frame_off,
-              hipStream_t s) {
-  if (batch < 0 || frame_off < 0 || frame_off + batch > h->max_batch)
-    return fail(DPX_ERR_ARG, "batch " + std::to_string(frame_off + batch) + " exceeds max_batch " + std::to_string(h->max_batch));
+int fill_sub(dpx_handle h, SubBatch& sb, const void* d_in, int32_t* d_labels, bool depth, float fx, float fy, float cx, float cy) {
+  sb = SubBatch{d_in, d_labels, fx, fy, cx, cy, 1.f, 1.f, false};
+  if (depth) {
+    DPX_HIP(hipSetDevice(h->device));
+    dpx_handle_s::FdEntry e{};
+    const int rc = prepare_intrinsics(h, fx, fy, cx, cy, &e);
+    if (rc) return rc;
+    sb.rx = e.rx; sb.ry = e.ry; sb.fd_ok = e.ok;
+  }
+  return DPX_OK;
+}
+
+int stage_fit(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool depth, hipStream_t s) {
+  const int batch = nsub * per_sub;
+  if (nsub < 1 || nsub > 8 || per_sub < 0 || batch > h->max_batch)
+    return fail(DPX_ERR_ARG, "batch " + std::to_string(batch) + " exceeds max_batch " + std::to_string(h->max_batch));
   DPX_HIP(hipSetDevice(h->device));
   if (batch == 0) return DPX_OK;
-  if (depth) {
-    const int rcp = prepare_intrinsics(h, fx, fy, cx, cy);
-    if (rcp) return rcp;
-  }
-  dpx::Params prm = h->prm;
-  prm.batch = batch;
-  prm.fx = fx; prm.fy = fy; prm.cx = cx; prm.cy = cy;
-  h->last_intr[0] = fx; h->last_intr[1] = fy; h->last_intr[2] = cx; h->last_intr[3] = cy;
   const bool prof = h->profiling;
   hipEvent_t* ev = h->ev[h->prof_calls % dpx_handle_s::kProfSlots];
   // DPX_SKIP=<letters f r l>: timing-only diagnostics that leave out a stage (results are garbage); tools/stage_cost.sh
   static const char* skip = std::getenv("DPX_SKIP");
   const bool skip_f = skip && std::strchr(skip, 'f');
   if (prof) DPX_HIP(hipEventRecord(ev[0], s));
-  if (prm.C > 0 && !skip_f) {
-    dpx_cell* out = h->d_cells + static_cast<size_t>(frame_off) * prm.C;
-    if (depth)
-      launch_planefit_depth(h, prm, d_in, out, s);
-    else
-      launch_planefit_cloud(h, prm, d_in, out, s);
+  if (h->prm.C > 0 && !skip_f) {
+    bool one_launch = depth && depth_fast_path(h->prm);
+    for (int j = 1; j < nsub && one_launch; ++j) one_launch = subs[j].fd_ok == subs[0].fd_ok;
+    if (one_launch) {
+      dpx::Params prm = h->prm;
+      prm.batch = batch;
+      dpx::PfGroup grp{};
+      for (int j = 0; j < 8; ++j) {
+        const SubBatch& b = subs[j < nsub ? j : 0];
+        grp.in[j] = b.d_in;
+        grp.fx[j] = b.fx; grp.fy[j] = b.fy; grp.cx[j] = b.cx; grp.cy[j] = b.cy; grp.rx[j] = b.rx; grp.ry[j] = b.ry;
+      }
+      grp.per_sub = per_sub;
+      launch_planefit_depth_group(prm, grp, h->d_cells, s, subs[0].fd_ok);
+    } else {
+      for (int j = 0; j < nsub; ++j) {
+        dpx::Params prm = h->prm;
+        prm.batch = per_sub;
+        prm.fx = subs[j].fx; prm.fy = subs[j].fy; prm.cx = subs[j].cx; prm.cy = subs[j].cy;
+        dpx_cell* out = h->d_cells + static_cast<size_t>(j) * per_sub * prm.C;
+        if (depth && depth_fast_path(prm)) {
+          dpx::PfGroup grp{};
+          for (int q = 0; q < 8; ++q) {
+            grp.in[q] = subs[j].d_in;
+            grp.fx[q] = subs[j].fx; grp.fy[q] = subs[j].fy; grp.cx[q] = subs[j].cx; grp.cy[q] = subs[j].cy;
+            grp.rx[q] = subs[j].rx; grp.ry[q] = subs[j].ry;
+          }
+          grp.per_sub = per_sub;
+          launch_planefit_depth_group(prm, grp, out, s, subs[j].fd_ok);
+        } else if (depth) {
+          launch_planefit<true>(prm, subs[j].d_in, out, s);
+        } else {
+          launch_planefit_cloud(h, prm, subs[j].d_in, out, s);
+        }
+      }
+    }
   }
   if (prof) DPX_HIP(hipEventRecord(ev[1], s));
   return DPX_OK;
@@ -309,7 +357,6 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   if (batch == 0) return DPX_OK;
   dpx::Params prm = h->prm;
   prm.batch = batch;
-  prm.fx = h->last_intr[0]; prm.fy = h->last_intr[1]; prm.cx = h->last_intr[2]; prm.cy = h->last_intr[3];
   const bool prof = h->profiling;
   hipEvent_t* ev = h->ev[h->prof_calls % dpx_handle_s::kProfSlots];
   static const char* skip = std::getenv("DPX_SKIP");
@@ -393,6 +440,7 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
     dpx::Params ps = prm;
     ps.batch = per_sub;
     for (int j = 0; j < nsub; ++j) {
+      ps.fx = subs[j].fx; ps.fy = subs[j].fy; ps.cx = subs[j].cx; ps.cy = subs[j].cy;
       dpx::RefineArgs ra{};
       ra.input = subs[j].d_in;
       ra.cell_labels = h->d_cell_labels + static_cast<size_t>(j) * per_sub * prm.C;
@@ -428,9 +476,11 @@ int run_pipeline(dpx_handle h, const void* d_in, bool depth, int batch, float fx
   h->last_stream = s;
   h->last_batch = batch;
   if (batch == 0) return DPX_OK;
-  int rc = stage_fit(h, d_in, depth, batch, fx, fy, cx, cy, 0, s);
+  SubBatch sb;
+  int rc = fill_sub(h, sb, d_in, d_labels, depth, fx, fy, cx, cy);
   if (rc) return rc;
-  const SubBatch sb{d_in, d_labels};
+  rc = stage_fit(h, &sb, 1, batch, depth, s);
+  if (rc) return rc;
   return stage_rest(h, &sb, 1, batch, depth, s);
 }
 
@@ -656,7 +706,7 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
     h->regions_tier = -1;
     if (!(v1 && v1[0] == '1') && !(force && force[0] == '1') && nb < 4600) {
       const int Ci = static_cast<int>(C), nbi = static_cast<int>(nb);
-      const dpx::R2Layout l2 = dpx::r2_layout(2, Ci, nbi), l1 = dpx::r2_layout(1, Ci, nbi), l0 = dpx::r2_layout(0, Ci, nbi);
+      const dpx::R2Layout l2 = dpx::r2_layout(2, Ci, nbi, nh), l1 = dpx::r2_layout(1, Ci, nbi, nh), l0 = dpx::r2_layout(0, Ci, nbi, nh);
       if (C < 65000 && std::max<size_t>(l2.tail_end, l2.image_end + 8 * pad2) <= kLdsLimit && !want_lean && !want_gst) {
         h->regions_tier = 2;
         h->sort_pad = static_cast<int>(pad2);
@@ -916,8 +966,9 @@ int dpx_get_planes(dpx_handle h, int32_t frame, dpx_plane* out, int32_t cap, int
 int dpx_prepare_intrinsics(dpx_handle h, float fx, float fy, float cx, float cy, int32_t* fast_division) {
   if (!h) return fail(DPX_ERR_ARG, "null handle");
   DPX_HIP(hipSetDevice(h->device));
-  const int rc = prepare_intrinsics(h, fx, fy, cx, cy);
-  if (rc == DPX_OK && fast_division) *fast_division = h->fd_ok ? 1 : 0;
+  dpx_handle_s::FdEntry e{};
+  const int rc = prepare_intrinsics(h, fx, fy, cx, cy, &e);
+  if (rc == DPX_OK && fast_division) *fast_division = e.ok ? 1 : 0;
   return rc;
 }
 
@@ -949,7 +1000,7 @@ int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_
 // ---- streamed pipeline: `slots` groups of `group` batches in flight, one stream and one scratch set per slot ------
 struct dpx_pipeline_s {
   std::vector<dpx_handle> slots;
-  std::vector<std::vector<SubBatch>> pending;  // per slot: submissions whose plane fit ran, region stage not yet
+  std::vector<std::vector<SubBatch>> pending;  // per slot: submissions recorded, not launched yet
   std::vector<char> pending_depth;             // per slot: input form of the pending submissions (1 depth, 0 cloud)
   int group = 1, batch = 0;
   long long submitted = 0;
@@ -960,7 +1011,9 @@ namespace {
 int pipeline_flush(dpx_pipeline p, size_t k) {
   if (p->pending[k].empty()) return DPX_OK;
   dpx_handle h = p->slots[k];
-  const int rc = stage_rest(h, p->pending[k].data(), static_cast<int>(p->pending[k].size()), p->batch, p->pending_depth[k] != 0, h->stream);
+  const int nsub = static_cast<int>(p->pending[k].size());
+  int rc = stage_fit(h, p->pending[k].data(), nsub, p->batch, p->pending_depth[k] != 0, h->stream);
+  if (rc == DPX_OK) rc = stage_rest(h, p->pending[k].data(), nsub, p->batch, p->pending_depth[k] != 0, h->stream);
   p->pending[k].clear();
   return rc;
 }
@@ -1015,13 +1068,16 @@ int pipeline_submit(dpx_pipeline p, const void* d_in, bool depth, int32_t batch,
     n = p->submitted;
     k = static_cast<size_t>((n / p->group) % static_cast<long long>(p->slots.size()));
   }
-  ++p->submitted;
   const int j = static_cast<int>(n % p->group);
   dpx_handle h = p->slots[k];
-  int rc = stage_fit(h, d_in, depth, batch, fx, fy, cx, cy, j * p->batch, h->stream);
+  // the submission is only recorded here: the plane fit of the whole group is ONE launch, issued with the region
+  // stage when the group is full (or at dpx_pipeline_sync)
+  SubBatch sb;
+  int rc = fill_sub(h, sb, d_in, static_cast<int32_t*>(d_labels), depth, fx, fy, cx, cy);
   if (rc) return rc;
+  ++p->submitted;
   p->pending_depth[k] = depth ? 1 : 0;
-  p->pending[k].push_back(SubBatch{d_in, static_cast<int32_t*>(d_labels)});
+  p->pending[k].push_back(sb);
   if (j == p->group - 1) rc = pipeline_flush(p, k);
   return rc;
 }
@@ -1086,37 +1142,45 @@ int dpx_get_kernel_ms(dpx_handle h, float* ms) {
   return DPX_OK;
 }
 
-int dpx_time_planefit(dpx_handle h, const void* d_in, int32_t input_kind, int32_t batch, float fx, float fy, float cx,
-                      float cy, int32_t iters, void* hip_stream, float* avg_ms) {
-  if (!h || !d_in || !avg_ms || iters < 1) return fail(DPX_ERR_ARG, "bad argument");
-  if (batch < 1 || batch > h->max_batch) return fail(DPX_ERR_ARG, "batch out of range");
+int dpx_time_planefit_group(dpx_handle h, const void* const* d_in, int32_t nsub, int32_t input_kind, int32_t per_sub, float fx,
+                            float fy, float cx, float cy, int32_t iters, void* hip_stream, float* avg_ms) {
+  if (!h || !d_in || !avg_ms || iters < 1 || nsub < 1 || nsub > 8) return fail(DPX_ERR_ARG, "bad argument");
+  if (per_sub < 1 || nsub * per_sub > h->max_batch) return fail(DPX_ERR_ARG, "batch out of range");
   DPX_HIP(hipSetDevice(h->device));
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
-  dpx::Params prm = h->prm;
-  prm.batch = batch;
-  prm.fx = fx; prm.fy = fy; prm.cx = cx; prm.cy = cy;
-  hipEvent_t a, b;
-  DPX_HIP(hipEventCreate(&a));
-  DPX_HIP(hipEventCreate(&b));
-  DPX_HIP(hipEventRecord(a, s));
-  if (input_kind == 0) {
-    const int rcp = prepare_intrinsics(h, fx, fy, cx, cy);
-    if (rcp) return rcp;
+  SubBatch subs[8];
+  for (int j = 0; j < nsub; ++j) {
+    if (!d_in[j]) return fail(DPX_ERR_ARG, "null input buffer");
+    // (the one-time verification of the reciprocal division synchronises: it happens here, before the timing)
+    const int rc = fill_sub(h, subs[j], d_in[j], nullptr, input_kind == 0, fx, fy, cx, cy);
+    if (rc) return rc;
   }
-  for (int i = 0; i < iters; ++i) {
-    if (input_kind == 0)
-      launch_planefit_depth(h, prm, d_in, h->d_cells, s);
-    else
-      launch_planefit_cloud(h, prm, d_in, h->d_cells, s);
-  }
-  DPX_HIP(hipEventRecord(b, s));
-  DPX_HIP(hipEventSynchronize(b));
+  const bool was_prof = h->profiling;
+  h->profiling = false;
+  hipEvent_t a = nullptr, b = nullptr;
   float ms = 0.f;
-  DPX_HIP(hipEventElapsedTime(&ms, a, b));
-  hipEventDestroy(a);
-  hipEventDestroy(b);
+  int rc = DPX_OK;
+  hipError_t e = hipEventCreate(&a);
+  if (e == hipSuccess) e = hipEventCreate(&b);
+  if (e == hipSuccess) e = hipEventRecord(a, s);
+  if (e == hipSuccess) {
+    for (int i = 0; i < iters && rc == DPX_OK; ++i) rc = stage_fit(h, subs, nsub, per_sub, input_kind == 0, s);
+    e = hipEventRecord(b, s);
+  }
+  if (e == hipSuccess) e = hipEventSynchronize(b);
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+  if (a) hipEventDestroy(a);
+  if (b) hipEventDestroy(b);
+  h->profiling = was_prof;
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(DPX_ERR_HIP, std::string("dpx_time_planefit: ") + hipGetErrorString(e));
   *avg_ms = ms / iters;
   return DPX_OK;
+}
+
+int dpx_time_planefit(dpx_handle h, const void* d_in, int32_t input_kind, int32_t batch, float fx, float fy, float cx,
+                      float cy, int32_t iters, void* hip_stream, float* avg_ms) {
+  return dpx_time_planefit_group(h, &d_in, 1, input_kind, batch, fx, fy, cx, cy, iters, hip_stream, avg_ms);
 }
 
 int64_t dpx_planefit_bytes(dpx_handle h, int32_t input_kind, int32_t batch) {

@@ -220,10 +220,12 @@ DPX_HD void eig3_hybrid(const Sym3& A, Eig3& o) {
       q21 = q21 * norm;
     }
   }
+#ifndef DPX_DIAG_NO_QL  // timing-only builds of tools/pfbench.hip leave the fallback out (wrong results for those cells)
   if (need_ql) {
     eig3_ql(A, o);
     return;
   }
+#endif
   o.w0 = w0;
   o.w1 = w1;
   o.w2 = w2;

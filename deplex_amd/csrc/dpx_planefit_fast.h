@@ -33,6 +33,10 @@ namespace dpx {
 #ifndef DPX_PF_WAVES
 #define DPX_PF_WAVES 4
 #endif
+// Diagnostic hook (tools/pfbench.hip defines it to record s_memtime stamps per wave); nothing in the product build.
+#ifndef DPX_PF_STAMP
+#define DPX_PF_STAMP(slot)
+#endif
 typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x4a8 __attribute__((ext_vector_type(4), aligned(8)));
 typedef uint32_t u32x2a __attribute__((ext_vector_type(2), aligned(4)));
@@ -253,6 +257,15 @@ __device__ __forceinline__ void load_cell_row(const uint16_t* rowp, uint32_t (&w
   if (d < DW) w[d] = rp[d];
 }
 
+// One launch fits the frames of up to 8 submissions (a dpx_pipeline group): frame f of the launch belongs to
+// submission f / per_sub, which has its own input buffer and its own intrinsics (and verified reciprocals).  The cell
+// records of all submissions are contiguous (frame-major), as the region kernels expect.
+struct PfGroup {
+  const void* in[8];
+  float fx[8], fy[8], cx[8], cy[8], rx[8], ry[8];
+  int per_sub;
+};
+
 // DIAG != 0 are timing-only instantiations (results are garbage): 1 = skip the plane fit / record maths (moments only),
 // 2 = loads + record store only.  Selected with DPX_PF_DIAG for tools/pf_breakdown.py; never used by the product path.
 template <int P, bool FASTDIV, int DIAG = 0>
@@ -261,8 +274,7 @@ template <int P, bool FASTDIV, int DIAG = 0>
 #else
 #define DPX_PF_VGPR_ATTR
 #endif
-__global__ __launch_bounds__(256, DPX_PF_WAVES) DPX_PF_VGPR_ATTR void k_planefit_depth(Params prm, const uint16_t* __restrict__ depth,
-                                                            dpx_cell* __restrict__ cells, float rx, float ry) {
+__global__ __launch_bounds__(256, DPX_PF_WAVES) DPX_PF_VGPR_ATTR void k_planefit_depth(Params prm, PfGroup grp, dpx_cell* __restrict__ cells) {
   static_assert(P % 2 == 0 && P >= 2, "even patch sizes only");
   constexpr int n = P * P;
   constexpr int DW = P / 2;  // dwords per cell row
@@ -282,9 +294,15 @@ __global__ __launch_bounds__(256, DPX_PF_WAVES) DPX_PF_VGPR_ATTR void k_planefit
   const int cr = rem / strips;
   const int cc = (rem - cr * strips) * 64 + lane;
   if (cc >= prm.nh) return;
+  // this wave's submission (wave-uniform: scalar loads from the argument block)
+  const int sub = __builtin_amdgcn_readfirstlane(frame / grp.per_sub);
+  prm.fx = grp.fx[sub]; prm.fy = grp.fy[sub]; prm.cx = grp.cx[sub]; prm.cy = grp.cy[sub];
+  const float rx = grp.rx[sub], ry = grp.ry[sub];
+  const uint16_t* depth = static_cast<const uint16_t*>(grp.in[sub]);
 
   const int row0 = cr * P, col0 = cc * P;
-  const uint16_t* src = depth + static_cast<long long>(frame) * prm.N + static_cast<long long>(row0) * prm.W + col0;
+  const uint16_t* src = depth + static_cast<long long>(frame - sub * grp.per_sub) * prm.N + static_cast<long long>(row0) * prm.W + col0;
+  DPX_PF_STAMP(0)
 
   float cxj[P];
   bool all_neg_x = true, all_neg_y = true;
@@ -366,6 +384,7 @@ __global__ __launch_bounds__(256, DPX_PF_WAVES) DPX_PF_VGPR_ATTR void k_planefit
   }
 
   if (A2 > 0 && n == A2) { acc.sx.fold(); acc.sy.fold(); acc.sz.fold(); }
+  DPX_PF_STAMP(1)
   float sum[3], pp[6];
   sum[0] = (acc.sx.c[0] + acc.sx.c[2]) + (acc.sx.c[1] + acc.sx.c[3]);
   sum[1] = (acc.sy.c[0] + acc.sy.c[2]) + (acc.sy.c[1] + acc.sy.c[3]);
@@ -403,6 +422,7 @@ __global__ __launch_bounds__(256, DPX_PF_WAVES) DPX_PF_VGPR_ATTR void k_planefit
   dst[1] = s4[1];
   dst[2] = s4[2];
   dst[3] = s4[3];
+  DPX_PF_STAMP(2)
 }
 
 // ---- organised-cloud input (the reference API's own input, plane_extractor.h:48): 12 B/point, no back-projection --

@@ -75,7 +75,10 @@ __host__ __device__ constexpr int stage_floats(int tier) { return kRW * stage_en
 struct R2Layout {
   uint32_t hist, cursor, bin_start, nzlist, flags, binof, qpos, queue, order, image_end, stage, tail_end;
 };
-__host__ __device__ inline R2Layout r2_layout(int tier, int C, int nb) {
+// The BFS and the seed scan read the flag byte / queue position of a cell's four neighbours WITHOUT clamping the index
+// (an index outside the grid is masked by the in-edge bit of that non-existent neighbour): `nh` guard bytes in front
+// of and behind the flag array (and the arrays that follow it) keep every such read inside the allocation.
+__host__ __device__ inline R2Layout r2_layout(int tier, int C, int nb, int nh) {
   R2Layout L{};
   uint32_t o = 192;  // header words
   L.hist = o; o += 4u * nb;
@@ -84,7 +87,9 @@ __host__ __device__ inline R2Layout r2_layout(int tier, int C, int nb) {
   o = (o + 3u) & ~3u;
   L.nzlist = o; o += 2u * nb;
   o = (o + 3u) & ~3u;
+  if (o < static_cast<uint32_t>(nh)) o = (static_cast<uint32_t>(nh) + 3u) & ~3u;  // flags[c - nh] stays in front of flags
   L.flags = o; o += static_cast<uint32_t>(C);
+  if (tier == 0) o += static_cast<uint32_t>(nh);  // flags[c + nh]: tiers 1/2 have 2*C bytes of qpos behind the flags
   o = (o + 3u) & ~3u;
   if (tier == 2) { L.binof = o; o += 2u * C; }
   o = (o + 3u) & ~3u;
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
   extern __shared__ __align__(16) unsigned char smem[];
-  const R2Layout lay = r2_layout(TIER, C, nb);
+  const R2Layout lay = r2_layout(TIER, C, nb, nh);
   int* hdr = reinterpret_cast<int*>(smem);  // 48 ints: 0 planar count, 1 tail, 2 ngrow, 3 ncand, 5 nnz bins, 16.. wave counts
   int* hist = reinterpret_cast<int*>(smem + lay.hist);
   int* cursor = reinterpret_cast<int*>(smem + lay.cursor);  // END of bin b's cell list
@@ -806,6 +811,12 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
   }
   const int pv_room = GST ? (pv_off < lay.flags + static_cast<uint32_t>(C) ? static_cast<int>(lay.flags + C - pv_off) : 0) : 4 * C;
   const bool fast = nplanes * 32 <= pv_room && nplanes * wpr <= kMatWords;
+  // The merge walk below is one wave's work, and so is what follows it for a frame of a few thousand cells: when the
+  // walk does not need the workgroup (no CSR build, no fused label expansion), waves 1.. end here and give their
+  // registers and wave slots back to the chip; wave 0 finishes the frame alone, without further workgroup barriers.
+  const bool solo = !DBG && !rx.labels_out[0] && (nplanes == 0 || fast);
+  if (solo && wid != 0) return;
+  const int tstride = solo ? 64 : kRT;
   const int gw = nh - 1, gh = nv - 1;
   const int gtotal = gw > 0 && gh > 0 ? gw * gh : 0;
   // merge test of the row plane (pnx.., pd) against a column plane (plane_extractor.cpp:405-412)
@@ -1035,17 +1046,17 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
   }
-  __syncthreads();
+  if (!solo) __syncthreads();
   t_p5 = DPX_STAMP();
   // ---------------- P6: merged label per cell (toImageLabels' lookup, plane_extractor.cpp:464-465); records --------
-  for (int c = tid; c < C; c += kRT) {
+  for (int c = tid; c < C; c += tstride) {
     const int L = lab16[c];
     const int fin = (L == 0 || nplanes == 0) ? 0 : merge[L - 1] + 1;
     cell_labels[c] = fin;
     lab16[c] = static_cast<idx_t>(fin);  // final labels stay in LDS for the fused expansion below
   }
   if (nplanes > 0)
-    for (int i = tid; i < nplanes; i += kRT) planes[i].merge_label = merge[i];
+    for (int i = tid; i < nplanes; i += tstride) planes[i].merge_label = merge[i];
   if (rx.labels_out[0]) {
     // Fused toImageLabels (plane_extractor.cpp:455-470), W % 4 == 0: this workgroup writes its frame's label map with
     // 16-byte stores straight from the LDS-resident cell labels.  Done here (on the few CUs that run region growing,

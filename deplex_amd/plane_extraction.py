@@ -213,19 +213,30 @@ class PlaneExtractor:
                                                  C.byref(ms)))
         return ms.value
 
+    def time_planefit_group(self, d_in_ptrs, input_kind: int, per_sub: int, fx, fy, cx, cy, iters: int, stream: int = 0) -> float:
+        """One plane-fit launch over len(d_in_ptrs) device buffers of per_sub frames each (the launch shape of a
+        Pipeline group), repeated `iters` times on `stream`; average ms per launch from HIP events on that stream."""
+        ms = C.c_float()
+        arr = (C.c_void_p * len(d_in_ptrs))(*[int(p) for p in d_in_ptrs])
+        _capi.check(_capi.lib().dpx_time_planefit_group(self._h, arr, len(d_in_ptrs), input_kind, per_sub, fx, fy, cx, cy,
+                                                       iters, stream, C.byref(ms)))
+        return ms.value
+
     def planefit_bytes(self, input_kind: int, batch: int) -> int:
         return int(_capi.lib().dpx_planefit_bytes(self._h, input_kind, batch))
 
 
 class Pipeline:
     """Streamed, pipelined processing of depth batches that already live in device memory (dpx_pipeline_*):
-    `slots` groups of `group` submissions in flight, one stream per slot; plane fits run per submission, region growing
-    and label expansion once per group.  Results are complete after sync()."""
+    `slots` groups of `group` submissions in flight, one stream per slot; a group is launched when it is full (or at
+    sync()): one plane-fit launch over all its frames, then region growing and label expansion.  Results are complete
+    after sync()."""
 
     def __init__(self, image_height: int, image_width: int, config: Optional[Config] = None, *, batch: int = 64,
                  slots: int = 16, group: int = 1, device: int = 0):
         self._p = C.c_void_p()
         cfg = config if config is not None else Config()
+        self.config, self.device = cfg, int(device)
         self.image_height, self.image_width, self.batch, self.slots = int(image_height), int(image_width), int(batch), int(slots)
         self.group = max(1, min(8, int(group)))
         _capi.check(_capi.lib().dpx_pipeline_create(C.byref(cfg._c), self.image_height, self.image_width, self.batch,
@@ -252,7 +263,9 @@ class Pipeline:
         nh, nv = C.c_int32(), C.c_int32()
         _capi.check(_capi.lib().dpx_grid_dims(ex._h, C.byref(nh), C.byref(nv)))
         ex.nh, ex.nv = nh.value, nv.value
+        ex.config, ex.device = self.config, self.device
         ex._borrowed = True
+        ex._owner = self  # the view's handle lives inside the pipeline: keep it alive as long as the view
         return ex
 
     def __del__(self):

@@ -133,10 +133,12 @@ int dpx_process_depth_batch_device(dpx_handle h, const void* d_depth, int32_t ba
 int dpx_process_pcd_batch_device(dpx_handle h, const void* d_xyz, int32_t batch, void* d_labels, void* hip_stream);
 
 /* Streamed processing (the reference's examples/process_sequence.cpp:30-53 loop, pipelined).  `slots` groups of
- * `group` (1..8) submissions are in flight, each slot with its own scratch and stream.  Every submission's plane fit is
- * launched at once; region growing + label expansion run once per group, for all its frames in one launch (the GPU
- * executes only a handful of kernels concurrently, so one latency-bound region launch per small batch wastes those
- * slots; group = 1 restores launch-per-submission).  Submissions must all have the batch size given at creation.
+ * `group` (1..8) submissions are in flight, each slot with its own scratch and stream.  A submission is recorded and
+ * the whole group is launched when it is full (or at dpx_pipeline_sync): ONE plane-fit launch over all its frames (each
+ * submission keeps its own input buffer and intrinsics), then region growing and label expansion, also one launch
+ * sequence per group (the GPU executes only a handful of kernels concurrently and a launch per small batch leaves the
+ * chip under-filled at its start and end; group = 1 restores launch-per-submission).  Submissions must all have the
+ * batch size given at creation.
  * submit() is asynchronous on device pointers; results of a submission are complete after dpx_pipeline_sync() (which
  * also flushes a partially filled group).  The caller must not reuse d_depth / d_labels of a submission before that.
  * dpx_pipeline_slot() exposes the per-slot handle (frames of a slot = its group's submissions back to back). */
@@ -179,6 +181,10 @@ int dpx_get_kernel_ms(dpx_handle h, float* ms /* DPX_K_COUNT */);
  * average duration in ms measured with HIP events on that stream (input_kind: 0 depth uint16, 1 xyz float32). */
 int dpx_time_planefit(dpx_handle h, const void* d_in, int32_t input_kind, int32_t batch, float fx, float fy,
                       float cx, float cy, int32_t iters, void* hip_stream, float* avg_ms);
+/* The same for a pipeline group: ONE launch over `nsub` (1..8) device buffers of `per_sub` frames each, the launch
+ * shape dpx_pipeline uses (nsub * per_sub <= max_batch of the handle). */
+int dpx_time_planefit_group(dpx_handle h, const void* const* d_in, int32_t nsub, int32_t input_kind, int32_t per_sub,
+                            float fx, float fy, float cx, float cy, int32_t iters, void* hip_stream, float* avg_ms);
 /* Algorithmic bytes one plane-fit launch moves for `batch` frames (input + cell records). */
 int64_t dpx_planefit_bytes(dpx_handle h, int32_t input_kind, int32_t batch);
 

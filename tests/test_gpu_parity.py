@@ -455,6 +455,42 @@ def test_multistream_pipeline(D, oracle):
         del pipe
 
 
+def test_pipeline_group_with_mixed_intrinsics(D, oracle):
+    """Submissions of ONE pipeline group may carry different intrinsics: every sub-batch is fitted, and (with
+    ransac_refinement on) re-projected by the refinement, with its own fx/fy/cx/cy — also when the plane fit of the
+    whole group runs as one launch."""
+    import torch
+    h, w, B = 240, 320, 2
+    ia = synth.intrinsics_for(h, w)
+    ib = tuple(float(np.float32(v)) for v in (ia[0] * 1.07, ia[1] * 0.93, ia[2] + 3.25, ia[3] - 2.5))
+    dev = torch.device("cuda", 0)
+    batches = [synth.synth_batch(B, h, w, seed0=300 + 10 * i) for i in range(4)]
+    intrs = [ia, ib, ib, ia]
+    d_in = [torch.from_numpy(b.view(np.int16)).to(dev) for b in batches]
+    oracle.set_math("devmath")
+    for refine in (0, 1):
+        ocfg = oracle.default_config(ransac_refinement=refine)
+        cfg = to_cfg(D, ocfg)
+        refs = [oracle.process_depth_batch(ocfg, b, *k, threads=2) for b, k in zip(batches, intrs)]
+        ocells = [oracle.process(ocfg, h, w, oracle.backproject(b[0], *k), debug=True)[1] for b, k in zip(batches, intrs)]
+        for group in (1, 2, 4):
+            d_out = [torch.full((B, h * w), -1, dtype=torch.int32, device=dev) for _ in range(4)]
+            pipe = D.Pipeline(h, w, cfg, batch=B, slots=2, group=group)
+            for i in range(4):
+                pipe.submit_depth(d_in[i].data_ptr(), B, *intrs[i], d_out[i].data_ptr())
+            pipe.sync()
+            ngroups = (4 + group - 1) // group
+            for i in range(4):
+                assert np.array_equal(d_out[i].cpu().numpy(), refs[i]), f"refine {refine} group {group} batch {i}"
+                gi = i // group
+                if gi + 2 >= ngroups:  # this submission's group is the last one its slot processed: records still there
+                    assert_cells_equal(pipe.slot(gi % 2).cells((i % group) * B), ocells[i])
+            view = pipe.slot(0)
+            del pipe  # the view keeps the pipeline (and its handle) alive
+            assert view.frame_stats(0)["segments"] >= 0 and view.config is cfg
+            del view
+
+
 def test_host_batches_with_records(D, oracle):
     """Larger host-pointer batches (depth, cloud, lean tier, refinement): labels, per-frame records and statistics of
     every frame."""
