@@ -64,6 +64,7 @@ struct dpx_handle_s {
   size_t refine_lds = 0;
   int* d_refine_cells = nullptr;        // refinement of frames whose cell list does not fit LDS: [B][C]
   unsigned long long* d_dbg = nullptr;  // diagnostic phase stamps (dpx_debug_region_phases)
+  unsigned long long* d_res = nullptr;  // diagnostic (DPX_RESIDENCY=1): workgroup lifetimes of the three region launches
   float4* d_lds_img = nullptr;          // split region kernel: LDS image per frame
   bool regions_split = false;
   float* d_mse_c = nullptr;
@@ -73,7 +74,7 @@ struct dpx_handle_s {
   size_t lds2_img = 0, lds2_p1 = 0, lds2_p2 = 0, lds2_p3 = 0;  // split form: image, and the three launches' allocations
   int sort_pad = 0;                          // tier 2: slots of the in-LDS seed-list sort (power of two >= C)
   // variant switches, read from the environment at create (tests and diagnostics)
-  bool opt_nofuse = false, opt_labels_v1 = false, opt_cloud_nolds = false;
+  bool opt_nofuse = false, opt_labels_v1 = false, opt_cloud_nolds = false, opt_prep_v1 = false;
   int opt_csr_chunk = 64;
   int Cpad = 0;                              // tiers 1/0: sort slots per frame (power of two >= C)
   unsigned long long* d_sort_keys = nullptr;  // [B][Cpad]
@@ -101,6 +102,7 @@ struct dpx_handle_s {
   bool ev_created = false;
   long long prof_calls = 0;
   int last_batch = 0;
+  long long fit_calls = 0;
 };
 
 namespace {
@@ -125,6 +127,7 @@ void free_all(dpx_handle h) {
   hipFree(h->d_merge);
   hipFree(h->d_stats);
   hipFree(h->d_dbg);
+  hipFree(h->d_res);
   hipFree(h->d_mt_init);
   hipFree(h->d_lds_img);
   hipFree(h->d_mse_c);
@@ -143,6 +146,15 @@ void free_all(dpx_handle h) {
     for (auto& e : slot)
       if (e) hipEventDestroy(e);
   if (h->stream) hipStreamDestroy(h->stream);
+}
+
+int device_cus() {  // compute units of the current device (persistent launches size their grids with it)
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  return cus;
 }
 
 bool fast_shape(const dpx::Params& prm) {
@@ -183,7 +195,12 @@ int prepare_intrinsics(dpx_handle h, float fx, float fy, float cx, float cy, dpx
 template <int P>
 void launch_planefit_fast(const dpx::Params& prm, const dpx::PfGroup& grp, dpx_cell* d_cells, hipStream_t s, bool fastdiv) {
   const long long waves = static_cast<long long>(prm.batch) * prm.nv * ((prm.nh + 63) / 64);
-  const unsigned blocks = static_cast<unsigned>((waves + 3) / 4);
+  unsigned blocks = static_cast<unsigned>((waves + 3) / 4);
+  // DPX_PF_RESIDENT=n: persistent launch with at most n workgroups per CU (see k_planefit_depth); default 0 = one wave
+  // per task.  Measured: the pipeline's throughput does not depend on n (1..4), a launch on its own is 15-25 % slower
+  // with n = 3 (static task lists leave a tail), so the plain launch stays the default.
+  static const int resident = std::getenv("DPX_PF_RESIDENT") ? std::atoi(std::getenv("DPX_PF_RESIDENT")) : 0;
+  if (resident > 0 && blocks > static_cast<unsigned>(resident * device_cus())) blocks = static_cast<unsigned>(resident * device_cus());
   static const int diag = std::getenv("DPX_PF_DIAG") ? std::atoi(std::getenv("DPX_PF_DIAG")) : 0;
   if (P == 10 && diag == 1)
     hipLaunchKernelGGL((dpx::k_planefit_depth<10, true, 1>), dim3(blocks), dim3(256), 0, s, prm, grp, d_cells);
@@ -295,7 +312,7 @@ int fill_sub(dpx_handle h, SubBatch& sb, const void* d_in, int32_t* d_labels, bo
   return DPX_OK;
 }
 
-int stage_fit(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool depth, hipStream_t s) {
+int stage_fit(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool depth, hipStream_t s, bool allow_skip = true) {
   const int batch = nsub * per_sub;
   if (nsub < 1 || nsub > 8 || per_sub < 0 || batch > h->max_batch)
     return fail(DPX_ERR_ARG, "batch " + std::to_string(batch) + " exceeds max_batch " + std::to_string(h->max_batch));
@@ -305,7 +322,10 @@ int stage_fit(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool de
   hipEvent_t* ev = h->ev[h->prof_calls % dpx_handle_s::kProfSlots];
   // DPX_SKIP=<letters f r l>: timing-only diagnostics that leave out a stage (results are garbage); tools/stage_cost.sh
   static const char* skip = std::getenv("DPX_SKIP");
-  const bool skip_f = skip && std::strchr(skip, 'f');
+  // 'F': the plane fit runs only the first two times on a handle, so that the later (timed) calls of the other stages
+  // still work on real cell records
+  const bool skip_f = allow_skip && skip && (std::strchr(skip, 'f') || (std::strchr(skip, 'F') && h->fit_calls >= 2));
+  ++h->fit_calls;
   if (prof) DPX_HIP(hipEventRecord(ev[0], s));
   if (h->prm.C > 0 && !skip_f) {
     bool one_launch = depth && depth_fast_path(h->prm);
@@ -377,6 +397,7 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   const bool fuse_labels = (h->regions_tier == 2 || h->regions_tier == 1) && (prm.W & 3) == 0 && !h->opt_nofuse && !skip_l && !skip_r;
   dpx::Regions2Extra rx{};
   rx.mse_c = h->d_mse_c; rx.cand_grow = h->d_cand_grow; rx.dbg = h->d_dbg; rx.lds_img = h->d_lds_img;
+  rx.res = h->d_res;
   rx.img_bytes = static_cast<int>(h->lds2_img);
   rx.sort_pad = h->sort_pad;
   rx.csr_chunk = h->opt_csr_chunk;
@@ -397,7 +418,10 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
     hipLaunchKernelGGL((dpx::k_regions2<0, true, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
   else if (h->regions_tier == 2 && h->regions_split) {
     const bool skip_p2 = skip && std::strchr(skip, '2'), skip_p3 = skip_p2 || (skip && std::strchr(skip, '3'));
-    hipLaunchKernelGGL((dpx::k_regions2<2, false, 1>), dim3(batch), dim3(dpx::kRT), h->lds2_p1, s, prm, rb, rx);
+    if (h->opt_prep_v1)
+      hipLaunchKernelGGL((dpx::k_regions2<2, false, 1>), dim3(batch), dim3(dpx::kRT), h->lds2_p1, s, prm, rb, rx);
+    else
+      hipLaunchKernelGGL(dpx::k_region_prep, dim3(batch), dim3(dpx::kRT), h->lds2_p1, s, prm, rb, rx);
     if (!skip_p2) hipLaunchKernelGGL((dpx::k_regions2<2, false, 2>), dim3(batch), dim3(64), h->lds2_p2, s, prm, rb, rx);
     if (!skip_p3) hipLaunchKernelGGL((dpx::k_regions2<2, false, 3>), dim3(batch), dim3(dpx::kRT), h->lds2_p3, s, prm, rb, rx);
   } else if (h->regions_tier == 2)
@@ -421,8 +445,15 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
       for (int j = 0; j < 8; ++j) outs.out[j] = j < nsub ? subs[j].d_labels : nullptr;
       outs.per_out = per_sub;
       const int extra = prm.H > prm.nv * prm.P ? 1 : 0;
-      if (prm.nv + extra > 0)
-        hipLaunchKernelGGL(dpx::k_labels_rows, dim3(batch, prm.nv + extra), dim3(256), 0, s, prm, h->d_cell_labels, outs);
+      if (prm.nv + extra > 0) {
+        // DPX_LAB_RESIDENT=n: at most n blocks per CU, each walking a task list (see k_labels_rows); default 0 = one block
+        // per task (measured: 13.5 us per 64 frames on its own against 14.4 with n = 1..8, no difference in the pipeline)
+        static const int resident = std::getenv("DPX_LAB_RESIDENT") ? std::atoi(std::getenv("DPX_LAB_RESIDENT")) : 0;
+        const long long tasks = static_cast<long long>(batch) * (prm.nv + extra);
+        long long blocks = tasks;
+        if (resident > 0 && blocks > static_cast<long long>(resident) * device_cus()) blocks = static_cast<long long>(resident) * device_cus();
+        hipLaunchKernelGGL(dpx::k_labels_rows, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, prm, h->d_cell_labels, outs, prm.nv + extra);
+      }
     } else {
       dpx::Params ps = prm;
       ps.batch = per_sub;
@@ -684,6 +715,7 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
   h->opt_nofuse = std::getenv("DPX_FUSED_LABELS") == nullptr;  // fusing the label expansion into the region tail measured 3-5 % slower
   h->opt_labels_v1 = std::getenv("DPX_LABELS_V1") != nullptr;
   h->opt_cloud_nolds = std::getenv("DPX_CLOUD_NOLDS") != nullptr;
+  h->opt_prep_v1 = std::getenv("DPX_PREP_V1") != nullptr;  // test hook: tier-2 preparation with the whole image in LDS
   if (const char* e = std::getenv("DPX_CSR_CHUNK")) {  // test hook: force the wide-row walk of the merge phase
     const int v = std::atoi(e);
     h->opt_csr_chunk = v < 0 ? 0 : (v > 64 ? 64 : v);
@@ -711,7 +743,7 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
         h->regions_tier = 2;
         h->sort_pad = static_cast<int>(pad2);
         h->lds2_img = l2.image_end;
-        h->lds2_p1 = l2.image_end + 8 * pad2;
+        h->lds2_p1 = h->opt_prep_v1 ? l2.image_end + 8 * pad2 : dpx::r2_prep_lds_bytes(l2, Ci);
         h->lds2_p2 = l2.image_end;
         h->lds2_p3 = l2.tail_end;
         h->lds2_bytes = std::max<size_t>(l2.tail_end, l2.image_end + 8 * pad2);
@@ -761,6 +793,10 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
     A(dev_alloc(&h->d_gqpos, B * C));
     A(dev_alloc(&h->d_gqueue, B * C));
   }
+  if (std::getenv("DPX_RESIDENCY")) {
+    A(dev_alloc(&h->d_res, B * 4));
+    if (rc == DPX_OK) (void)hipMemset(h->d_res, 0, B * 4 * sizeof(unsigned long long));
+  }
   if (rc == DPX_OK && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
     rc = fail(DPX_ERR_HIP, "hipStreamCreate failed");
   if (rc == DPX_OK && h->lds_bytes > 48 * 1024) {
@@ -799,7 +835,7 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
       A(dev_alloc(&h->d_lds_img, B * (h->lds2_img / 16)));
       const void* fns[3];
       if (h->regions_tier == 2) {
-        fns[0] = reinterpret_cast<const void*>(dpx::k_regions2<2, false, 1>);
+        fns[0] = h->opt_prep_v1 ? reinterpret_cast<const void*>(dpx::k_regions2<2, false, 1>) : reinterpret_cast<const void*>(dpx::k_region_prep);
         fns[1] = reinterpret_cast<const void*>(dpx::k_regions2<2, false, 2>);
         fns[2] = reinterpret_cast<const void*>(dpx::k_regions2<2, false, 3>);
       } else {
@@ -997,6 +1033,23 @@ int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_
   return DPX_OK;
 }
 
+int dpx_debug_residency(dpx_handle h, double* out3) {  // out3[3]: the grow launch's lifetime in 100 MHz ticks
+  if (!h || !out3) return fail(DPX_ERR_ARG, "null argument");
+  if (!h->d_res) return fail(DPX_ERR_ARG, "set DPX_RESIDENCY=1 before dpx_create");
+  DPX_HIP(hipSetDevice(h->device));
+  DPX_HIP(hipStreamSynchronize(h->last_stream));
+  std::vector<unsigned long long> v(static_cast<size_t>(h->max_batch) * 4);
+  DPX_HIP(hipMemcpy(v.data(), h->d_res, v.size() * 8, hipMemcpyDeviceToHost));
+  for (int k = 0; k < 4; ++k) {
+    double s = 0;
+    int n = 0;
+    for (int f = 0; f < h->last_batch; ++f)
+      if (v[static_cast<size_t>(f) * 4 + k]) { s += static_cast<double>(v[static_cast<size_t>(f) * 4 + k]); ++n; }
+    out3[k] = n ? s / n : 0.0;
+  }
+  return DPX_OK;
+}
+
 // ---- streamed pipeline: `slots` groups of `group` batches in flight, one stream and one scratch set per slot ------
 struct dpx_pipeline_s {
   std::vector<dpx_handle> slots;
@@ -1164,7 +1217,7 @@ int dpx_time_planefit_group(dpx_handle h, const void* const* d_in, int32_t nsub,
   if (e == hipSuccess) e = hipEventCreate(&b);
   if (e == hipSuccess) e = hipEventRecord(a, s);
   if (e == hipSuccess) {
-    for (int i = 0; i < iters && rc == DPX_OK; ++i) rc = stage_fit(h, subs, nsub, per_sub, input_kind == 0, s);
+    for (int i = 0; i < iters && rc == DPX_OK; ++i) rc = stage_fit(h, subs, nsub, per_sub, input_kind == 0, s, false);
     e = hipEventRecord(b, s);
   }
   if (e == hipSuccess) e = hipEventSynchronize(b);

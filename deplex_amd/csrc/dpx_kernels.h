@@ -454,68 +454,56 @@ __global__ __launch_bounds__(256) void k_labels(Params prm, const int32_t* __res
 }
 
 // K6, tuned form for W % 4 == 0: one 256-thread block per (frame, cell row).  The P image rows of a cell row carry the
-// same label pattern, so a thread builds its 4-pixel int4 once (labels of the cell row staged in LDS) and stores it to
-// all P rows: ~1 store per 16 output bytes and almost no arithmetic.  blockIdx.y == nv handles the image rows below
-// the last full cell row (H % P != 0), which are 0.
+// same label pattern, so a thread builds its 4-pixel int4 once and stores it to all P rows: ~1 store per 16 output
+// bytes and almost no arithmetic.  The cell labels of the row (nh * 4 bytes) are read straight from global memory
+// (L1/L2 hits): the kernel allocates NO LDS, so its blocks also fit on CUs whose LDS is filled by region workgroups.
+// blockIdx.y == nv handles the image rows below the last full cell row (H % P != 0), which are 0.
 // Frames of a grouped submission go to up to eight output buffers (`per_out` frames each).
 struct LabelOuts {
   int32_t* out[8];
   int per_out;
 };
-__global__ __launch_bounds__(256) void k_labels_rows(Params prm, const int32_t* __restrict__ cell_labels, LabelOuts outs) {
-  __shared__ int32_t cl[1024];
-  const int frame = blockIdx.x;
+// Block b takes the (frame, cell row) tasks b, b + gridDim.x, ...: one block per task by default, a bounded persistent
+// grid with DPX_LAB_RESIDENT=n (an experiment: label blocks filling every wave slot of the chip turned out not to be
+// what keeps the other groups' kernels from overlapping with this one).
+__global__ __launch_bounds__(256) void k_labels_rows(Params prm, const int32_t* __restrict__ cell_labels, LabelOuts outs, int rows_per_frame) {
+ const int ntasks = prm.batch * rows_per_frame;
+ for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
+  const int frame = task / rows_per_frame;
   const int sub = frame / outs.per_out;
   int32_t* __restrict__ dst = outs.out[sub] + static_cast<long long>(frame - sub * outs.per_out) * prm.N;
-  const int cr = blockIdx.y;
+  const int cr = task - frame * rows_per_frame;
   const int W4 = prm.W >> 2;
   const bool tail = cr >= prm.nv;  // rows outside the cell grid
   const int row_begin = tail ? prm.nv * prm.P : cr * prm.P;
   const int row_end = tail ? prm.H : row_begin + prm.P;
-  const int32_t* src = cell_labels + static_cast<long long>(frame) * prm.C + static_cast<long long>(cr) * prm.nh;
-  for (int c0 = 0; c0 < prm.nh || c0 == 0; c0 += 1024) {  // cell rows wider than 1024 cells are processed in slabs
-    __syncthreads();
-    for (int c = threadIdx.x; c < 1024; c += 256) cl[c] = (!tail && c0 + c < prm.nh) ? src[c0 + c] : 0;
-    __syncthreads();
-    const int col_lo = c0 * prm.P, col_hi = (c0 + 1024) * prm.P;
-    for (int q = threadIdx.x; q < W4; q += 256) {
-      const int col = q << 2;
-      if (col + 3 < col_lo || col >= col_hi) continue;
-      if (col < col_lo || col + 3 >= col_hi) {  // chunk straddles a slab boundary (only for nh > 1024): scalar path
-        for (int i = 0; i < 4; ++i) {
-          const int cc = (col + i) / prm.P;
-          if (cc >= c0 && cc < c0 + 1024) {
-            const int32_t v = cl[cc - c0];
-            for (int r = row_begin; r < row_end; ++r) dst[static_cast<long long>(r) * prm.W + col + i] = v;
-          }
-        }
-        continue;
-      }
-      int cc = col / prm.P;
-      int rem = col - cc * prm.P;
-      int4 v;
-      int32_t* vp = reinterpret_cast<int32_t*>(&v);
+  const int32_t* __restrict__ src = cell_labels + static_cast<long long>(frame) * prm.C + static_cast<long long>(tail ? 0 : cr) * prm.nh;
+  for (int q = threadIdx.x; q < W4; q += 256) {
+    const int col = q << 2;
+    int cc = col / prm.P;
+    int rem = col - cc * prm.P;
+    int4 v;
+    int32_t* vp = reinterpret_cast<int32_t*>(&v);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        vp[i] = cl[cc - c0];
-        if (++rem == prm.P) {
-          rem = 0;
-          ++cc;
-        }
-      }
-      // streaming stores: the label map is written once and not read again by this pipeline
-      for (int r = row_begin; r < row_end; ++r) {
-#ifdef DPX_LABELS_PLAIN_STORE
-        *reinterpret_cast<int4*>(dst + static_cast<long long>(r) * prm.W + col) = v;
-#else
-        typedef int i32x4 __attribute__((ext_vector_type(4)));
-        const i32x4 nv = {v.x, v.y, v.z, v.w};
-        __builtin_nontemporal_store(nv, reinterpret_cast<i32x4*>(dst + static_cast<long long>(r) * prm.W + col));
-#endif
+    for (int i = 0; i < 4; ++i) {
+      vp[i] = (!tail && cc < prm.nh) ? src[cc] : 0;  // columns right of the cell grid (W % P != 0) are 0
+      if (++rem == prm.P) {
+        rem = 0;
+        ++cc;
       }
     }
-    if (prm.nh <= 1024) break;
+    // streaming stores: the label map is written once and not read again by this pipeline
+    for (int r = row_begin; r < row_end; ++r) {
+#ifdef DPX_LABELS_PLAIN_STORE
+      *reinterpret_cast<int4*>(dst + static_cast<long long>(r) * prm.W + col) = v;
+#else
+      typedef int i32x4 __attribute__((ext_vector_type(4)));
+      const i32x4 nv = {v.x, v.y, v.z, v.w};
+      __builtin_nontemporal_store(nv, reinterpret_cast<i32x4*>(dst + static_cast<long long>(r) * prm.W + col));
+#endif
+    }
   }
+ }
 }
 
 // DepthImage::toPointCloud (utils/depth_image.cpp:55-78) as a stand-alone kernel for the utils API.

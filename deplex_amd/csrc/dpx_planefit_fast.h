@@ -245,6 +245,18 @@ __device__ __forceinline__ void load_cell_row(const uint16_t* rowp, uint32_t (&w
   const uint32_t* rp = reinterpret_cast<const uint32_t*>(rowp);
   int d = 0;
 #pragma unroll
+#ifdef DPX_PF_NT_LOADS  // experiment: depth pixels are read once — keep them out of the way of the data the region kernels re-read
+  for (; d + 4 <= DW; d += 4) {
+    const u32x4a v = __builtin_nontemporal_load(reinterpret_cast<const u32x4a*>(rp + d));
+    w[d] = v.x; w[d + 1] = v.y; w[d + 2] = v.z; w[d + 3] = v.w;
+  }
+  if (d + 2 <= DW) {
+    const u32x2a v = __builtin_nontemporal_load(reinterpret_cast<const u32x2a*>(rp + d));
+    w[d] = v.x; w[d + 1] = v.y;
+    d += 2;
+  }
+  if (d < DW) w[d] = __builtin_nontemporal_load(rp + d);
+#else
   for (; d + 4 <= DW; d += 4) {
     const u32x4a v = *reinterpret_cast<const u32x4a*>(rp + d);
     w[d] = v.x; w[d + 1] = v.y; w[d + 2] = v.z; w[d + 3] = v.w;
@@ -255,6 +267,7 @@ __device__ __forceinline__ void load_cell_row(const uint16_t* rowp, uint32_t (&w
     d += 2;
   }
   if (d < DW) w[d] = rp[d];
+#endif
 }
 
 // One launch fits the frames of up to 8 submissions (a dpx_pipeline group): frame f of the launch belongs to
@@ -268,13 +281,13 @@ struct PfGroup {
 
 // DIAG != 0 are timing-only instantiations (results are garbage): 1 = skip the plane fit / record maths (moments only),
 // 2 = loads + record store only.  Selected with DPX_PF_DIAG for tools/pf_breakdown.py; never used by the product path.
-template <int P, bool FASTDIV, int DIAG = 0>
 #ifdef DPX_PF_VGPR
 #define DPX_PF_VGPR_ATTR __attribute__((amdgpu_num_vgpr(DPX_PF_VGPR)))
 #else
 #define DPX_PF_VGPR_ATTR
 #endif
-__global__ __launch_bounds__(256, DPX_PF_WAVES) DPX_PF_VGPR_ATTR void k_planefit_depth(Params prm, PfGroup grp, dpx_cell* __restrict__ cells) {
+template <int P, bool FASTDIV, int DIAG>
+__device__ __forceinline__ void pf_depth_task(Params prm, const PfGroup& grp, dpx_cell* __restrict__ cells, const long long wave, const int lane) {
   static_assert(P % 2 == 0 && P >= 2, "even patch sizes only");
   constexpr int n = P * P;
   constexpr int DW = P / 2;  // dwords per cell row
@@ -285,10 +298,7 @@ __global__ __launch_bounds__(256, DPX_PF_WAVES) DPX_PF_VGPR_ATTR void k_planefit
   constexpr int FULL_A = ((A2 / P) / 4) * 4, FULL_B = ((P - 1) / 4) * 4;
   constexpr int FULL = FULL_A < FULL_B ? FULL_A : FULL_B;
   const int strips = (prm.nh + 63) >> 6;
-  const long long wave = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
   const long long per_frame = static_cast<long long>(prm.nv) * strips;
-  if (wave >= per_frame * prm.batch) return;
   const int frame = static_cast<int>(wave / per_frame);
   const int rem = static_cast<int>(wave - frame * per_frame);
   const int cr = rem / strips;
@@ -423,6 +433,18 @@ __global__ __launch_bounds__(256, DPX_PF_WAVES) DPX_PF_VGPR_ATTR void k_planefit
   dst[2] = s4[2];
   dst[3] = s4[3];
   DPX_PF_STAMP(2)
+}
+
+// Every wave walks the list of (frame, cell row, 64-cell strip) tasks with the grid stride: the host either starts one
+// wave per task (default) or, with DPX_PF_RESIDENT=n, a persistent grid of n workgroups per CU (an experiment in keeping
+// part of the register file free for the other groups' region workgroups; it changed nothing in the pipeline).
+template <int P, bool FASTDIV, int DIAG = 0>
+__global__ __launch_bounds__(256, DPX_PF_WAVES) DPX_PF_VGPR_ATTR void k_planefit_depth(Params prm, PfGroup grp, dpx_cell* __restrict__ cells) {
+  const int lane = threadIdx.x & 63;
+  const long long total = static_cast<long long>(prm.batch) * prm.nv * ((prm.nh + 63) >> 6);
+  const long long stride = static_cast<long long>(gridDim.x) * 4;
+  for (long long wave = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6); wave < total; wave += stride)
+    pf_depth_task<P, FASTDIV, DIAG>(prm, grp, cells, wave, lane);
 }
 
 // ---- organised-cloud input (the reference API's own input, plane_extractor.h:48): 12 B/point, no back-projection --

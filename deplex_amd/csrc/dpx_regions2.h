@@ -121,6 +121,7 @@ struct Regions2Extra {
   uint32_t* g_qpos;         // tier 0: [B][C] queue position of each cell
   int sort_pad;             // tier 2: power of two >= C, slots of the in-LDS seed-list sort
   int csr_chunk;            // merge phase: rows with more adjacency entries than this (<= 64) use the bit-row walk
+  unsigned long long* res;  // diagnostic (DPX_RESIDENCY=1): [B][4] shader-clock lifetime of the frame's workgroup in launch 1, 2, 3
   int32_t* labels_out[8];   // non-null: the tail also expands the cell labels to the pixel label map (fused K6);
   int frames_per_out;       // frame f writes to labels_out[f / frames_per_out] (grouped submissions have one buffer each)
 };
@@ -156,6 +157,8 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
   __builtin_amdgcn_s_setprio(DPX_REGIONS_PRIO);  // latency-bound waves: win issue arbitration against co-resident streaming kernels
 #endif
   unsigned long long t_start = DPX_STAMP(), t_p0 = 0, t_p1 = 0, t_p2 = 0, t_p3 = 0, t_p4 = 0, t_p5 = 0;
+  const unsigned long long t_res = (PHASE > 0 && rx.res) ? static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) : 0ull;
+  const unsigned long long t_real = (PHASE == 2 && rx.res) ? static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()) : 0ull;
   unsigned long long a_argmax = 0, a_seed = 0, a_bfs = 0, a_rem = 0, n_steps = 0;
   const int frame = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -359,6 +362,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
   }  // PHASE <= 1
   if (PHASE == 1) {
     for (int i = tid; i < img_vec; i += static_cast<int>(blockDim.x)) img[i] = lds_v[i];
+    if (rx.res && tid == 0) rx.res[frame * 4 + 0] = static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - t_res;
     return;
   }
   const int planar_total = hdr[0];
@@ -667,6 +671,10 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
   __syncthreads();
   if (PHASE == 2) {
     for (int i = tid; i < img_vec; i += static_cast<int>(blockDim.x)) img[i] = lds_v[i];
+    if (rx.res && tid == 0) {
+      rx.res[frame * 4 + 1] = static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - t_res;
+      rx.res[frame * 4 + 3] = static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()) - t_real;  // 100 MHz ticks
+    }
     return;
   }
   const int activations = hdr[1], ngrow = hdr[2], ncand = hdr[3];
@@ -1094,6 +1102,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
     st.merges = merges;
     st.overflow = 0;
     rb.stats[frame] = st;
+    if (PHASE == 3 && rx.res) rx.res[frame * 4 + 2] = static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - t_res;
     if (DBG && rx.dbg) {
       unsigned long long* d = rx.dbg + static_cast<size_t>(frame) * 16;
       const unsigned long long t_end = DPX_STAMP();
@@ -1104,5 +1113,183 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
   }
 }
 #undef DPX_STAMP
+
+// ---- Tier-2 preparation of the phase-split form, LDS-lean -----------------------------------------------------------
+// Same results as k_regions2<2, ., 1> (the frame's LDS image for the grow launch, byte for byte where the grow and tail
+// launches read it), but the workgroup keeps only what the preparation itself works on in LDS: the header, the
+// histogram / list-bound arrays and the sort keys.  The per-cell arrays of the image (flag bytes, bins, queue
+// positions, seed lists) go straight to the image in global memory, and the keys are sorted with the all-ascending
+// ("normalised") bitonic network, which needs no padding to a power of two: comparators that would touch an index >= n
+// are simply skipped (the virtual keys there are +infinity and already in place).  For 640x480 that is 5 KB + 8 B per
+// planar cell <= 29.6 KB instead of 65 KB: five preparation workgroups per CU instead of two — the region launches
+// are bound by how many frames' LDS fit on the chip at a time.
+__host__ __device__ inline uint32_t r2_prep_keys_offset(const R2Layout& L) { return (L.flags + 7u) & ~7u; }
+__host__ __device__ inline uint32_t r2_prep_lds_bytes(const R2Layout& L, int C) { return r2_prep_keys_offset(L) + 8u * static_cast<uint32_t>(C); }
+
+__global__ __launch_bounds__(kRT) void k_region_prep(Params prm, RegionBufs rb, Regions2Extra rx) {
+#if DPX_REGIONS_PRIO
+  __builtin_amdgcn_s_setprio(DPX_REGIONS_PRIO);
+#endif
+  const unsigned long long t_res = rx.res ? static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) : 0ull;
+  const int frame = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int C = prm.C, nh = prm.nh, nv = prm.nv;
+  const int nb = prm.hist_B * prm.hist_B;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const R2Layout lay = r2_layout(2, C, nb, nh);
+  int* hdr = reinterpret_cast<int*>(smem);
+  int* hist = reinterpret_cast<int*>(smem + lay.hist);
+  int* cursor = reinterpret_cast<int*>(smem + lay.cursor);
+  uint16_t* bin_start = reinterpret_cast<uint16_t*>(smem + lay.bin_start);
+  uint16_t* nzlist = reinterpret_cast<uint16_t*>(smem + lay.nzlist);
+  unsigned long long* skeys = reinterpret_cast<unsigned long long*>(smem + r2_prep_keys_offset(lay));
+  // the frame's image in global memory, same byte offsets as the LDS image of the grow / tail launches
+  unsigned char* img = reinterpret_cast<unsigned char*>(rx.lds_img + static_cast<size_t>(frame) * (rx.img_bytes >> 4));
+  uint8_t* g_flags = img + lay.flags;
+  uint16_t* g_binof = reinterpret_cast<uint16_t*>(img + lay.binof);
+  uint16_t* g_qpos = reinterpret_cast<uint16_t*>(img + lay.qpos);
+  uint16_t* g_order = reinterpret_cast<uint16_t*>(img + lay.order);
+  const dpx_cell* cells = rb.cells + static_cast<size_t>(frame) * C;
+
+  for (int b = tid; b < nb; b += kRT) hist[b] = 0;
+  if (tid < 48) hdr[tid] = 0;
+  __syncthreads();
+  {
+    int planar_cnt = 0;
+    for (int c0 = 0; c0 < C; c0 += kRT) {  // (uniform trip count: the key compaction below uses wave ballots)
+      const int c = c0 + tid < C ? c0 + tid : C - 1;
+      const bool live = c0 + tid < C;
+      // fused K3 (k_cellgraph): planar bit, histogram bin and the four IN-edges of the growSeed predicate
+      // (plane_extractor.cpp:377-383) straight from the plane-fit records
+      const float4* rc = reinterpret_cast<const float4*>(cells + c);
+      const float4 q2 = rc[2], q3 = rc[3];  // {pp5, n0, n1, n2}, {d, mse, tol, info}
+      const uint32_t info = __float_as_uint(q3.w);
+      uint32_t fl = (info & CELL_PLANAR) ? F_UNASSIGNED : 0u;
+      const uint32_t bin1 = (info & CELL_PLANAR) ? (info >> 8) : 0u;
+      if (fl) {
+        const float4 q0 = rc[0];
+        const float nf = static_cast<float>(prm.n);
+        const float smx = q0.x / nf, smy = q0.y / nf, smz = q0.z / nf;  // mean_ = coord_sum_ / nr_pts_
+        const double tol_self = static_cast<double>(q3.z);
+        const int cr = c / nh, cc = c - cr * nh;
+        const int nbr[4] = {cr >= 1 ? c - nh : -1, cr + 1 < nv ? c + nh : -1, cc >= 1 ? c - 1 : -1, cc + 1 < nh ? c + 1 : -1};
+#pragma unroll
+        for (int dir = 0; dir < 4; ++dir) {
+          const int v = nbr[dir];
+          if (v < 0) continue;
+          const float4* rv = reinterpret_cast<const float4*>(cells + v);
+          const float4 v2 = rv[2], v3 = rv[3];
+          if (!(__float_as_uint(v3.w) & CELL_PLANAR)) continue;
+          const float cosf_ = dot3(q2.y, q2.z, q2.w, v2.y, v2.z, v2.w);  // same products/sum order as n_v . n_c
+          if (!(static_cast<double>(cosf_) >= static_cast<double>(prm.min_cos))) continue;
+          const double ti = static_cast<double>(dot3(v2.y, v2.z, v2.w, smx, smy, smz)) + static_cast<double>(v3.x);
+          if (ti * ti <= tol_self) fl |= (F_EDGE0 << dir);
+        }
+      }
+      // sort key of the seed lists (dpx_binsort.h): bin, then MSE, then cell id
+      const int kb = static_cast<int>(bin1) - 1;
+      const bool has = live && fl && kb >= 0 && kb < nb;
+      if (live) {
+        g_flags[c] = static_cast<uint8_t>(fl);
+        g_binof[c] = static_cast<uint16_t>(bin1);
+        g_qpos[c] = static_cast<uint16_t>(0xFFFFu);
+        if (fl & F_UNASSIGNED) {
+          ++planar_cnt;
+          if (kb >= 0 && kb < nb) atomicAdd(&hist[kb], 1);
+        }
+      }
+      const unsigned long long hm = __ballot(has);  // compact the keys (any order: they are sorted next)
+      int base = 0;
+      if (lane == 0 && hm) base = atomicAdd(&hdr[6], __popcll(hm));
+      base = __shfl(base, 0);
+      if (has)
+        skeys[base + __popcll(hm & lt_mask)] = (static_cast<unsigned long long>(kb) << kKeyBinShift) |
+                                               (static_cast<unsigned long long>(sort_mse_key(q3.y)) << kKeyCellBits) |
+                                               static_cast<unsigned long long>(c);
+    }
+    planar_cnt = wave_sum(planar_cnt);
+    if (lane == 0) atomicAdd(&hdr[0], planar_cnt);
+  }
+  __syncthreads();
+  if (wid == 0) {  // list bounds of every bin, compact list of the non-empty bins (ascending)
+    int carry = 0;
+    for (int base = 0; base < nb; base += 64) {
+      const int b = base + lane;
+      const int v = b < nb ? hist[b] : 0;
+      const int incl = wave_incl_scan(v, lane);
+      if (b < nb) {
+        bin_start[b] = static_cast<uint16_t>(carry + incl - v);
+        cursor[b] = carry + incl;
+      }
+      carry += __shfl(incl, 63);
+      const unsigned long long nzm = __ballot(v > 0);
+      if (v > 0) nzlist[hdr[5] + __popcll(nzm & lt_mask)] = static_cast<uint16_t>(b);
+      if (lane == 0) hdr[5] += __popcll(nzm);
+      wave_sync();
+    }
+    if (lane == 0) bin_start[nb] = static_cast<uint16_t>(carry);
+  }
+  __syncthreads();
+  // ---- all-ascending bitonic network on exactly n keys.  Stage k: blocks of k keys; first the "mirror" step (i against
+  // the block's k-1-i), then the half-cleaners j = k/4 .. 1 (i against i+j).  Steps whose pairs stay inside an aligned
+  // 128-key chunk are finished by one wave per chunk without workgroup barriers.
+  const int n = hdr[6];
+  auto cex = [&](int lo, int hi) {
+    if (hi < n) {
+      const unsigned long long a = skeys[lo], b = skeys[hi];
+      if (a > b) {
+        skeys[lo] = b;
+        skeys[hi] = a;
+      }
+    }
+  };
+  const int half = (n + 1) >> 1;  // pair indices that can have lo < n
+  for (int k = 2; (k >> 1) < n; k <<= 1) {
+    if (k <= 128) {
+      for (int cb = wid * 128; cb < n; cb += kRW * 128) {
+        {  // mirror step inside the chunk: pair p of the chunk -> block p / (k/2), offset p % (k/2)
+          const int hk = k >> 1;
+          const int blk = lane / hk, off = lane - blk * hk;
+          cex(cb + blk * k + off, cb + blk * k + (k - 1 - off));
+          wave_sync();
+        }
+        for (int j = k >> 2; j >= 1; j >>= 1) {
+          cex(cb + (((lane & ~(j - 1)) << 1) | (lane & (j - 1))), cb + ((((lane & ~(j - 1)) << 1) | (lane & (j - 1))) | j));
+          wave_sync();
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    {  // mirror step across the workgroup
+      const int hk = k >> 1;
+      for (int pi = tid; pi < ((n + k - 1) / k) * hk; pi += kRT) {
+        const int blk = pi / hk, off = pi - blk * hk;
+        cex(blk * k + off, blk * k + (k - 1 - off));
+      }
+      __syncthreads();
+    }
+    for (int j = k >> 2; j >= 64; j >>= 1) {
+      for (int pi = tid; pi < half + j; pi += kRT) cex(((pi & ~(j - 1)) << 1) | (pi & (j - 1)), (((pi & ~(j - 1)) << 1) | (pi & (j - 1))) | j);
+      __syncthreads();
+    }
+    for (int cb = wid * 128; cb < n; cb += kRW * 128) {
+      for (int j = 32; j >= 1; j >>= 1) {
+        cex(cb + (((lane & ~(j - 1)) << 1) | (lane & (j - 1))), cb + ((((lane & ~(j - 1)) << 1) | (lane & (j - 1))) | j));
+        wave_sync();
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += kRT) g_order[i] = static_cast<uint16_t>(skeys[i] & ((1u << kKeyCellBits) - 1u));
+  // header, histogram and list bounds: the first lay.flags bytes of the image (a multiple of 4)
+  {
+    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(smem);
+    uint32_t* d32 = reinterpret_cast<uint32_t*>(img);
+    for (int i = tid; i < static_cast<int>(lay.flags >> 2); i += kRT) d32[i] = s32[i];
+  }
+  if (rx.res && tid == 0) rx.res[frame * 4 + 0] = static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - t_res;
+}
 
 }  // namespace dpx

@@ -193,6 +193,10 @@ int64_t dpx_planefit_bytes(dpx_handle h, int32_t input_kind, int32_t batch);
  * sums over grows of arg-max, seed search, BFS, histogram removal, and the counters BFS steps, grows, candidates,
  * activations).  enable != 0 switches the diagnostic instantiation on for later calls; never used when timing. */
 int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_t* out16);
+/* Diagnostic (handles created with DPX_RESIDENCY=1 in the environment): average shader-clock lifetime of a frame's
+ * workgroup in the three region launches (preparation, grow, tail) over the frames of the last call — how long each
+ * holds its LDS while other kernels share the chip. */
+int dpx_debug_residency(dpx_handle h, double* out4 /* [3] = grow lifetime in 100 MHz real-time ticks */);
 
 /* Exercises dpx_math.h and the 3x3 eigensolver on the device (parity tests): n inputs each.
  * which: 0 atan2(a,b) 1 sin(a) 2 cos(a) 3 acos(a) 4 sqrt(a).  Host pointers. */
