@@ -91,6 +91,7 @@ SYMBOLS = {
     "dpx_time_planefit_group": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.POINTER(C.c_float)]),
     "dpx_planefit_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
     "dpx_debug_residency": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "dpx_debug_trace": (C.c_int, [C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "dpx_test_math": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     "dpx_test_eig3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
 }

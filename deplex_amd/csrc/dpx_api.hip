@@ -1033,6 +1033,18 @@ int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_
   return DPX_OK;
 }
 
+int dpx_debug_trace(int32_t device, uint64_t* d_buf, uint32_t cap_per_slot, uint32_t* counts) {
+  DPX_HIP(hipSetDevice(device));
+  DPX_HIP(hipDeviceSynchronize());
+  if (counts) DPX_HIP(hipMemcpyFromSymbol(counts, HIP_SYMBOL(dpx::g_trace_n), dpx::kTraceSlots * sizeof(unsigned int)));
+  unsigned long long* buf = reinterpret_cast<unsigned long long*>(d_buf);
+  static const std::vector<unsigned int> zeros(dpx::kTraceSlots, 0u);
+  DPX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(dpx::g_trace_n), zeros.data(), dpx::kTraceSlots * sizeof(unsigned int)));
+  DPX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(dpx::g_trace_cap), &cap_per_slot, sizeof(cap_per_slot)));
+  DPX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(dpx::g_trace), &buf, sizeof(buf)));
+  return DPX_OK;
+}
+
 int dpx_debug_residency(dpx_handle h, double* out3) {  // out3[3]: the grow launch's lifetime in 100 MHz ticks
   if (!h || !out3) return fail(DPX_ERR_ARG, "null argument");
   if (!h->d_res) return fail(DPX_ERR_ARG, "set DPX_RESIDENCY=1 before dpx_create");

@@ -19,6 +19,49 @@
 
 namespace dpx {
 
+// ---- diagnostic wave trace (dpx_debug_trace): every wave of the pipeline's kernels logs where and when it ran --------
+// Entry = 4 x u64: start and end in 100 MHz real-time ticks (s_memrealtime: one clock for the whole chip), the hardware
+// id (XCC << 32 | HW_ID: SE, CU, SIMD, wave slot), and kind | wave-in-block << 4 | blockIdx.x << 8.  A hardware wave slot
+// holds one wave at a time, so each slot owns a ring of entries and a plain counter — no atomics; the counter is
+// loaded when the wave starts and first needed when it ends, i.e. its latency hides behind the kernel.  Off (one
+// scalar load per wave) unless a buffer is installed.
+constexpr unsigned int kTraceSlots = 1u << 16;  // XCC (3) | SE, SH, CU bits of HW_ID (7) | SIMD (2) | wave slot (4)
+__device__ unsigned long long* g_trace = nullptr;
+__device__ unsigned int g_trace_cap = 0;  // entries per slot
+__device__ unsigned int g_trace_n[kTraceSlots] = {};
+enum TraceKind { TK_PLANEFIT = 1, TK_PREP = 2, TK_GROW = 3, TK_TAIL = 4, TK_LABELS = 5 };
+struct WaveTrace {
+  unsigned long long* base;
+  unsigned long long t0, id, what;
+  unsigned int slot, n;
+  __device__ __forceinline__ explicit WaveTrace(int kind) : base(nullptr) {
+    unsigned long long* t = g_trace;
+    if (t && (threadIdx.x & 63) == 0) {
+      const unsigned int xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20), hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+      slot = ((xcc & 7u) << 13) | (((hw >> 8) & 0x7Fu) << 6) | (((hw >> 4) & 3u) << 4) | (hw & 15u);
+      n = g_trace_n[slot];
+      base = t;
+      t0 = __builtin_amdgcn_s_memrealtime();
+      id = (static_cast<unsigned long long>(xcc) << 32) | hw;
+      what = static_cast<unsigned long long>(kind) | (static_cast<unsigned long long>(threadIdx.x >> 6) << 4) |
+             (static_cast<unsigned long long>(blockIdx.x) << 8);
+    }
+  }
+  __device__ __forceinline__ ~WaveTrace() {
+    if (base) {
+      const unsigned int cap = g_trace_cap;
+      if (n < cap) {
+        unsigned long long* e = base + 4ull * (static_cast<unsigned long long>(slot) * cap + n);
+        e[0] = t0;
+        e[1] = __builtin_amdgcn_s_memrealtime();
+        e[2] = id;
+        e[3] = what;
+        g_trace_n[slot] = n + 1;
+      }
+    }
+  }
+};
+
 struct Params {
   int H, W, P, nh, nv, C, N;  // image, patch, grid, cells per frame, pixels per frame
   int n;                      // points per cell = P*P
@@ -467,6 +510,7 @@ struct LabelOuts {
 // grid with DPX_LAB_RESIDENT=n (an experiment: label blocks filling every wave slot of the chip turned out not to be
 // what keeps the other groups' kernels from overlapping with this one).
 __global__ __launch_bounds__(256) void k_labels_rows(Params prm, const int32_t* __restrict__ cell_labels, LabelOuts outs, int rows_per_frame) {
+ WaveTrace trace_(TK_LABELS);
  const int ntasks = prm.batch * rows_per_frame;
  for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
   const int frame = task / rows_per_frame;

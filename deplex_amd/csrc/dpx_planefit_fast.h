@@ -440,6 +440,7 @@ __device__ __forceinline__ void pf_depth_task(Params prm, const PfGroup& grp, dp
 // part of the register file free for the other groups' region workgroups; it changed nothing in the pipeline).
 template <int P, bool FASTDIV, int DIAG = 0>
 __global__ __launch_bounds__(256, DPX_PF_WAVES) DPX_PF_VGPR_ATTR void k_planefit_depth(Params prm, PfGroup grp, dpx_cell* __restrict__ cells) {
+  WaveTrace trace_(TK_PLANEFIT);
   const int lane = threadIdx.x & 63;
   const long long total = static_cast<long long>(prm.batch) * prm.nv * ((prm.nh + 63) >> 6);
   const long long stride = static_cast<long long>(gridDim.x) * 4;

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
   using idx_t = typename std::conditional<GST, uint32_t, uint16_t>::type;
   constexpr uint32_t kNoPos = GST ? 0xFFFFFFFFu : 0xFFFFu;
   static_assert(PHASE == 0 || TIER >= 1, "the phase-split launches need the cell labels in LDS");
+  WaveTrace trace_(PHASE == 1 ? TK_PREP : (PHASE == 2 ? TK_GROW : TK_TAIL));
 #if DPX_REGIONS_PRIO
   __builtin_amdgcn_s_setprio(DPX_REGIONS_PRIO);  // latency-bound waves: win issue arbitration against co-resident streaming kernels
 #endif
@@ -1127,6 +1128,7 @@ __host__ __device__ inline uint32_t r2_prep_keys_offset(const R2Layout& L) { ret
 __host__ __device__ inline uint32_t r2_prep_lds_bytes(const R2Layout& L, int C) { return r2_prep_keys_offset(L) + 8u * static_cast<uint32_t>(C); }
 
 __global__ __launch_bounds__(kRT) void k_region_prep(Params prm, RegionBufs rb, Regions2Extra rx) {
+  WaveTrace trace_(TK_PREP);
 #if DPX_REGIONS_PRIO
   __builtin_amdgcn_s_setprio(DPX_REGIONS_PRIO);
 #endif

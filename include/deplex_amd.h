@@ -196,6 +196,12 @@ int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_
 /* Diagnostic (handles created with DPX_RESIDENCY=1 in the environment): average shader-clock lifetime of a frame's
  * workgroup in the three region launches (preparation, grow, tail) over the frames of the last call — how long each
  * holds its LDS while other kernels share the chip. */
+/* Diagnostic wave trace: installs a device buffer of 65536 slots x `cap_per_slot` entries (4 x uint64 each: start, end in
+ * 100 MHz ticks, XCC<<32 | HW_ID, kind | wave-in-block<<4 | blockIdx<<8; kinds 1 plane fit, 2 preparation, 3 grow,
+ * 4 tail, 5 labels) that every wave of the pipeline's kernels appends to (slot = its hardware wave slot: XCC, CU, SIMD,
+ * wave id); d_buf = NULL switches the trace off.  counts (65536 words) receives the entries written per slot since
+ * the previous call.  Synchronises the device. */
+int dpx_debug_trace(int32_t device, uint64_t* d_buf, uint32_t cap_per_slot, uint32_t* counts);
 int dpx_debug_residency(dpx_handle h, double* out4 /* [3] = grow lifetime in 100 MHz real-time ticks */);
 
 /* Exercises dpx_math.h and the 3x3 eigensolver on the device (parity tests): n inputs each.
