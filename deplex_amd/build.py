@@ -41,6 +41,20 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     return OUT
 
 
+def build_variant(name: str, defines=(), force: bool = False) -> Path:
+    """An experimental / diagnostic build of the same library under lib/variants/<name>.so (selected with DPX_LIB_PATH):
+    "trace" = -DDPX_TRACE, the wave trace of tools/wave_trace.py."""
+    if name == "trace" and not defines:
+        defines = ("DPX_TRACE",)
+    out = OUT.parent / "variants" / f"{name}.so"
+    if not force and out.exists() and all(s.stat().st_mtime <= out.stat().st_mtime for s in sources()):
+        return out
+    out.parent.mkdir(parents=True, exist_ok=True)
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    subprocess.run([hipcc, *FLAGS, *[f"-D{d}" for d in defines], str(SRC / "dpx_api.hip"), "-o", str(out)], check=True)
+    return out
+
+
 PYB_SRC = PKG / "cpp" / "pybind" / "deplex_pybind.cpp"
 
 

@@ -195,12 +195,7 @@ int prepare_intrinsics(dpx_handle h, float fx, float fy, float cx, float cy, dpx
 template <int P>
 void launch_planefit_fast(const dpx::Params& prm, const dpx::PfGroup& grp, dpx_cell* d_cells, hipStream_t s, bool fastdiv) {
   const long long waves = static_cast<long long>(prm.batch) * prm.nv * ((prm.nh + 63) / 64);
-  unsigned blocks = static_cast<unsigned>((waves + 3) / 4);
-  // DPX_PF_RESIDENT=n: persistent launch with at most n workgroups per CU (see k_planefit_depth); default 0 = one wave
-  // per task.  Measured: the pipeline's throughput does not depend on n (1..4), a launch on its own is 15-25 % slower
-  // with n = 3 (static task lists leave a tail), so the plain launch stays the default.
-  static const int resident = std::getenv("DPX_PF_RESIDENT") ? std::atoi(std::getenv("DPX_PF_RESIDENT")) : 0;
-  if (resident > 0 && blocks > static_cast<unsigned>(resident * device_cus())) blocks = static_cast<unsigned>(resident * device_cus());
+  const unsigned blocks = static_cast<unsigned>((waves + 3) / 4);
   static const int diag = std::getenv("DPX_PF_DIAG") ? std::atoi(std::getenv("DPX_PF_DIAG")) : 0;
   if (P == 10 && diag == 1)
     hipLaunchKernelGGL((dpx::k_planefit_depth<10, true, 1>), dim3(blocks), dim3(256), 0, s, prm, grp, d_cells);
@@ -1034,6 +1029,9 @@ int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_
 }
 
 int dpx_debug_trace(int32_t device, uint64_t* d_buf, uint32_t cap_per_slot, uint32_t* counts) {
+#ifndef DPX_TRACE
+  if (d_buf) return fail(DPX_ERR_ARG, "this build has no wave trace: use the -DDPX_TRACE variant (deplex_amd.build.build_variant('trace'))");
+#endif
   DPX_HIP(hipSetDevice(device));
   DPX_HIP(hipDeviceSynchronize());
   if (counts) DPX_HIP(hipMemcpyFromSymbol(counts, HIP_SYMBOL(dpx::g_trace_n), dpx::kTraceSlots * sizeof(unsigned int)));

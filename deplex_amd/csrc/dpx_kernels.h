@@ -23,13 +23,15 @@ namespace dpx {
 // Entry = 4 x u64: start and end in 100 MHz real-time ticks (s_memrealtime: one clock for the whole chip), the hardware
 // id (XCC << 32 | HW_ID: SE, CU, SIMD, wave slot), and kind | wave-in-block << 4 | blockIdx.x << 8.  A hardware wave slot
 // holds one wave at a time, so each slot owns a ring of entries and a plain counter — no atomics; the counter is
-// loaded when the wave starts and first needed when it ends, i.e. its latency hides behind the kernel.  Off (one
-// scalar load per wave) unless a buffer is installed.
+// loaded when the wave starts and first needed when it ends, i.e. its latency hides behind the kernel.  Compiled in
+// only with -DDPX_TRACE (deplex_amd/build.py build_variant("trace"), used by tools/wave_trace.py): the live values cost
+// the plane-fit kernel registers it does not have.
 constexpr unsigned int kTraceSlots = 1u << 16;  // XCC (3) | SE, SH, CU bits of HW_ID (7) | SIMD (2) | wave slot (4)
 __device__ unsigned long long* g_trace = nullptr;
 __device__ unsigned int g_trace_cap = 0;  // entries per slot
 __device__ unsigned int g_trace_n[kTraceSlots] = {};
 enum TraceKind { TK_PLANEFIT = 1, TK_PREP = 2, TK_GROW = 3, TK_TAIL = 4, TK_LABELS = 5 };
+#ifdef DPX_TRACE
 struct WaveTrace {
   unsigned long long* base;
   unsigned long long t0, id, what;
@@ -61,6 +63,11 @@ struct WaveTrace {
     }
   }
 };
+#else  // product build: the trace costs registers that the plane-fit kernel does not have to spare
+struct WaveTrace {
+  __device__ __forceinline__ explicit WaveTrace(int) {}
+};
+#endif
 
 struct Params {
   int H, W, P, nh, nv, C, N;  // image, patch, grid, cells per frame, pixels per frame

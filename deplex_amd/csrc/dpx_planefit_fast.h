@@ -435,17 +435,15 @@ __device__ __forceinline__ void pf_depth_task(Params prm, const PfGroup& grp, dp
   DPX_PF_STAMP(2)
 }
 
-// Every wave walks the list of (frame, cell row, 64-cell strip) tasks with the grid stride: the host either starts one
-// wave per task (default) or, with DPX_PF_RESIDENT=n, a persistent grid of n workgroups per CU (an experiment in keeping
-// part of the register file free for the other groups' region workgroups; it changed nothing in the pipeline).
+// One wave per (frame, cell row, 64-cell strip) task.  (A persistent grid walking a task list with the grid stride was
+// tried, to keep part of the register file free for the other groups' region workgroups: it made no difference in the
+// pipeline, and the loop around the body cost 119 scalar and 36 vector register spills.)
 template <int P, bool FASTDIV, int DIAG = 0>
 __global__ __launch_bounds__(256, DPX_PF_WAVES) DPX_PF_VGPR_ATTR void k_planefit_depth(Params prm, PfGroup grp, dpx_cell* __restrict__ cells) {
   WaveTrace trace_(TK_PLANEFIT);
-  const int lane = threadIdx.x & 63;
-  const long long total = static_cast<long long>(prm.batch) * prm.nv * ((prm.nh + 63) >> 6);
-  const long long stride = static_cast<long long>(gridDim.x) * 4;
-  for (long long wave = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6); wave < total; wave += stride)
-    pf_depth_task<P, FASTDIV, DIAG>(prm, grp, cells, wave, lane);
+  const long long wave = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (wave >= static_cast<long long>(prm.batch) * prm.nv * ((prm.nh + 63) >> 6)) return;
+  pf_depth_task<P, FASTDIV, DIAG>(prm, grp, cells, wave, threadIdx.x & 63);
 }
 
 // ---- organised-cloud input (the reference API's own input, plane_extractor.h:48): 12 B/point, no back-projection --

@@ -3,6 +3,10 @@ Prints time-averaged occupancy per SIMD / CU by kernel kind: resident waves, VGP
 could have taken another workgroup of each kind.   usage: python tools/wave_trace.py [steps] [DPX_SKIP letters]"""
 import os, sys, ctypes as C
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+from pathlib import Path as _P
+sys.path.insert(0, str(_P(__file__).resolve().parents[1]))
+from deplex_amd import build as _b
+os.environ["DPX_LIB_PATH"] = str(_b.build_variant("trace"))  # the product build carries no trace code
 if len(sys.argv) > 2: os.environ["DPX_SKIP"] = sys.argv[2]
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
