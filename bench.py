@@ -98,7 +98,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DPX_BENCH_STREAMS", 16)))
-    ap.add_argument("--group", type=int, default=int(os.environ.get("DPX_BENCH_GROUP", 8)), help="submissions per region-growing launch")
+    # submissions per launch sequence: 8 is 2 % faster in steady state (1.48 vs 1.45 M frames/s at 2000 steps); 5 divides
+    # short runs (the driver's 20 steps) into whole groups, worth 10 % there (1.19 vs 1.08 M) — measured, DESIGN.md section 5
+    ap.add_argument("--group", type=int, default=int(os.environ.get("DPX_BENCH_GROUP", 5)), help="submissions per launch sequence (1..8)")
     ap.add_argument("--prof-every", type=int, default=16, help="record per-kernel HIP events on every n-th slot")
     ap.add_argument("--roofline-iters", type=int, default=50)
     ap.add_argument("--no-cloud-roofline", action="store_true")

@@ -1105,6 +1105,10 @@ int dpx_pipeline_create(const dpx_config* cfg, int32_t image_height, int32_t ima
   }
   p->pending.resize(p->slots.size());
   p->pending_depth.assign(p->slots.size(), 1);
+  // HIP binds a stream to a hardware queue at its first use: do that here, once, for every slot, instead of inside the
+  // first groups a caller submits
+  for (auto h : p->slots) (void)hipMemsetAsync(h->d_stats, 0, sizeof(dpx_frame_stats), h->stream);
+  for (auto h : p->slots) (void)hipStreamSynchronize(h->stream);
   *out = p;
   return DPX_OK;
 }
