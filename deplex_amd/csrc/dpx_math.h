@@ -72,17 +72,17 @@ DPX_HD void sincos_small(double x, double* s, double* c) {
     *c = *s;
     return;
   }
-  if (x <= kPio4Hi) {
-    *s = ksin(x, 0.0);
-    *c = kcos(x, 0.0);
-    return;
-  }
-  // y = pi/2 - x, split into head + tail
-  double h = kPio2Hi - x;  // exact (Sterbenz)
-  double y = h + kPio2Lo;
-  double t = (h - y) + kPio2Lo;
-  *s = kcos(y, t);
-  *c = ksin(y, t);
+  // Above pi/4 the complement y = pi/2 - x (head + tail) is evaluated with the roles of sin and cos swapped.  Both
+  // cases run through ONE evaluation of each kernel with selected arguments (on a GPU the lanes of a wave fall on
+  // both sides of pi/4 and two separate branches would both be executed); the operations on each value are unchanged.
+  const bool small = x <= kPio4Hi;
+  const double h = kPio2Hi - x;  // exact (Sterbenz) where it is used
+  const double yc = h + kPio2Lo;
+  const double tc = (h - yc) + kPio2Lo;
+  const double y = small ? x : yc, t = small ? 0.0 : tc;
+  const double sv = ksin(y, t), cv = kcos(y, t);
+  *s = small ? sv : cv;
+  *c = small ? cv : sv;
 }
 
 // atan(a) for 0 <= a <= 1, returned as head + tail (tail only approximate).
@@ -146,7 +146,8 @@ DPX_HD double datan2(double y, double x) {
     return dsignbit(y) ? -z : z;
   }
   bool swap = ay > ax;
-  double a = swap ? ax / ay : ay / ax;
+  const double num = swap ? ax : ay, den = swap ? ay : ax;  // (one division, operands selected)
+  double a = num / den;
   z = atan01(a, &zt);
   if (swap) {  // pi/2 - z
     double h = kPio2Hi - z;

@@ -82,15 +82,24 @@ struct Chains8 {
   }
 };
 
-template <int P, bool FASTDIV>
+// ZI (depth input with n * 65535 < 2^24, i.e. P <= 16): every z is an integer below 2^16 and every partial sum of z
+// stays below 2^24, so all float additions of the z column are exact and the column sum is the same number in any
+// order — it is accumulated as an integer, two pixels per instruction (v_sad_u16 on the raw input dword), and
+// converted once.  The count of valid (non-zero) pixels is kept per 16-bit half (v_pk_min_u16 + v_pk_add_u16).
+typedef unsigned short dpx_u16x2 __attribute__((ext_vector_type(2)));
+template <int P, bool FASTDIV, bool ZI = false>
 struct CellAcc {
   static constexpr int n = P * P;
   static constexpr int A2 = (n / 8) * 8;
+  static_assert(!ZI || n <= 256, "integer z sums need n * 65535 < 2^24");
   Chains8 sx, sy, sz;
+  uint32_t zsum;      // ZI: sum of the raw depths
+  dpx_u16x2 vcnt2;    // ZI: valid pixels seen in the low / high halves of the input dwords
   float xx, xy, xz, yy, yz, zz;
   float fx0, fy0, fz0, lx, ly, lz;
   float hprev, vprev;
-  int hdisc, vdisc, valid_pts;
+  uint32_t disc;  // discontinuities: centre row in bits 0..15, centre column in bits 16..31 (one register: none to spare)
+  int valid_pts;
   bool folded;
 
   __device__ __forceinline__ void init() {
@@ -98,8 +107,27 @@ struct CellAcc {
     xx = xy = xz = yy = yz = zz = 0.f;
     fx0 = fy0 = fz0 = lx = ly = lz = 0.f;
     hprev = vprev = 0.f;
-    hdisc = vdisc = valid_pts = 0;
+    disc = 0u;
+    valid_pts = 0;
     folded = false;
+    zsum = 0u;
+    vcnt2 = dpx_u16x2{0, 0};
+  }
+  // ZI: both pixels of one input dword
+  __device__ __forceinline__ void dword(uint32_t w) {
+    zsum = __builtin_amdgcn_sad_u16(w, 0u, zsum);
+    uint32_t m;  // min(depth, 1) per half: the compiler expands the vector form into compares and selects
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(w), "s"(0x00010001u));
+    dpx_u16x2 h;
+    __builtin_memcpy(&h, &m, 4);
+    vcnt2 += h;
+  }
+  __device__ __forceinline__ bool continuous(int max_disc) const {  // (at most P discontinuities per scan: no carry)
+    return (static_cast<int>(disc & 0xFFFFu) < max_disc) && (static_cast<int>(disc >> 16) < max_disc);
+  }
+  __device__ __forceinline__ int valid_count() const { return ZI ? static_cast<int>(vcnt2.x) + static_cast<int>(vcnt2.y) : valid_pts; }
+  __device__ __forceinline__ float z_sum() const {
+    return ZI ? static_cast<float>(zsum) : (sz.c[0] + sz.c[2]) + (sz.c[1] + sz.c[3]);
   }
 
   // One pixel.  KM = k & 7 and the position flags are compile-time; the row index may be a runtime value.
@@ -110,7 +138,7 @@ struct CellAcc {
     asm volatile("" : "+v"(z));
     const float x = div_const<FASTDIV>(cx_j * z, prm.fx, rx);
     const float y = div_const<FASTDIV>(cy_i * z, prm.fy, ry);
-    valid_pts += zi != 0u;
+    if (!ZI) valid_pts += zi != 0u;
     point<J, KM, TAIL, TAILIDX, FIRST, LAST, HROW>(x, y, z, prm);
   }
 
@@ -122,21 +150,21 @@ struct CellAcc {
     if (HROW) {  // centre row, in j order (cell_segment.cpp:62-76)
       if (J == 0) hprev = z;
       if (z > 0 && __builtin_fabsf(z - hprev) < prm.disc_thr) hprev = z;
-      else if (z > 0) ++hdisc;
+      else if (z > 0) disc += 1u;
     }
     if (J == P / 2) {  // centre column, in i order (cell_segment.cpp:78-91); vprev is preset to the row-0 value
       if (z > 0 && __builtin_fabsf(z - vprev) < prm.disc_thr) vprev = z;
-      else if (z > 0) ++vdisc;
+      else if (z > 0) disc += 0x10000u;
     }
     if (!TAIL) {
       sx.c[KM] = sx.c[KM] + x;
       sy.c[KM] = sy.c[KM] + y;
-      sz.c[KM] = sz.c[KM] + z;
+      if (!ZI) sz.c[KM] = sz.c[KM] + z;
     } else {  // trailing 4-packet after the 8-wide part: fold first, then add to chains 0..3
-      if (TAILIDX == 0 && A2 > 0) { sx.fold(); sy.fold(); sz.fold(); }
+      if (TAILIDX == 0 && A2 > 0) { sx.fold(); sy.fold(); if (!ZI) sz.fold(); }
       sx.c[TAILIDX] = sx.c[TAILIDX] + x;
       sy.c[TAILIDX] = sy.c[TAILIDX] + y;
-      sz.c[TAILIDX] = sz.c[TAILIDX] + z;
+      if (!ZI) sz.c[TAILIDX] = sz.c[TAILIDX] + z;
     }
     if (n + 6 >= 20 || !FIRST) {
       xx = x * x + xx; xy = x * y + xy; xz = x * z + xz; yy = y * y + yy; yz = y * z + yz; zz = z * z + zz;
@@ -167,6 +195,7 @@ struct CellAcc {
     constexpr bool FIRST = K == 0;
     constexpr bool LAST = K == n - 1;
     const uint32_t zi = (J & 1) ? (w[J >> 1] >> 16) : (w[J >> 1] & 0xFFFFu);
+    if (ZI && (J & 1) == 0) dword(w[J >> 1]);
     if (STATIC_I >= 0) {
       pixel<J, KM, TAIL, TAILIDX, FIRST, LAST, STATIC_I == P / 2>(zi, cxj[J], cy_i, prm, rx, ry);
     } else if (is_hrow) {
@@ -185,7 +214,7 @@ struct CellAcc {
     {
       asm volatile("" : "+v"(sx.c[0]), "+v"(sx.c[1]), "+v"(sx.c[2]), "+v"(sx.c[3]), "+v"(sx.c[4]), "+v"(sx.c[5]), "+v"(sx.c[6]), "+v"(sx.c[7]));
       asm volatile("" : "+v"(sy.c[0]), "+v"(sy.c[1]), "+v"(sy.c[2]), "+v"(sy.c[3]), "+v"(sy.c[4]), "+v"(sy.c[5]), "+v"(sy.c[6]), "+v"(sy.c[7]));
-      asm volatile("" : "+v"(sz.c[0]), "+v"(sz.c[1]), "+v"(sz.c[2]), "+v"(sz.c[3]), "+v"(sz.c[4]), "+v"(sz.c[5]), "+v"(sz.c[6]), "+v"(sz.c[7]));
+      if (!ZI) asm volatile("" : "+v"(sz.c[0]), "+v"(sz.c[1]), "+v"(sz.c[2]), "+v"(sz.c[3]), "+v"(sz.c[4]), "+v"(sz.c[5]), "+v"(sz.c[6]), "+v"(sz.c[7]));
       asm volatile("" : "+v"(xx), "+v"(xy), "+v"(xz), "+v"(yy), "+v"(yz), "+v"(zz));
     }
   }
@@ -297,12 +326,14 @@ __device__ __forceinline__ void pf_depth_task(Params prm, const PfGroup& grp, dp
   // rows [0, FULL) are whole 4-row groups below A2 that do not contain the last row (its last point is needed)
   constexpr int FULL_A = ((A2 / P) / 4) * 4, FULL_B = ((P - 1) / 4) * 4;
   constexpr int FULL = FULL_A < FULL_B ? FULL_A : FULL_B;
+  // frame, cell row and strip are wave-uniform: kept in scalar registers (the vector registers are all spoken for)
   const int strips = (prm.nh + 63) >> 6;
-  const long long per_frame = static_cast<long long>(prm.nv) * strips;
-  const int frame = static_cast<int>(wave / per_frame);
-  const int rem = static_cast<int>(wave - frame * per_frame);
-  const int cr = rem / strips;
-  const int cc = (rem - cr * strips) * 64 + lane;
+  const int per_frame = prm.nv * strips;
+  const int frame = __builtin_amdgcn_readfirstlane(static_cast<int>(wave / per_frame));
+  const int rem = __builtin_amdgcn_readfirstlane(static_cast<int>(wave - static_cast<long long>(frame) * per_frame));
+  const int cr = __builtin_amdgcn_readfirstlane(rem / strips);
+  const int cc0 = __builtin_amdgcn_readfirstlane((rem - cr * strips) * 64);
+  const int cc = cc0 + lane;
   if (cc >= prm.nh) return;
   // this wave's submission (wave-uniform: scalar loads from the argument block)
   const int sub = __builtin_amdgcn_readfirstlane(frame / grp.per_sub);
@@ -315,16 +346,10 @@ __device__ __forceinline__ void pf_depth_task(Params prm, const PfGroup& grp, dp
   DPX_PF_STAMP(0)
 
   float cxj[P];
-  bool all_neg_x = true, all_neg_y = true;
 #pragma unroll
-  for (int j = 0; j < P; ++j) {
-    cxj[j] = static_cast<float>(col0 + j) - prm.cx;
-    all_neg_x = all_neg_x && (__builtin_signbit(cxj[j]) != __builtin_signbit(prm.fx));
-  }
-  for (int i = 0; i < P; ++i)
-    all_neg_y = all_neg_y && (__builtin_signbit(static_cast<float>(row0 + i) - prm.cy) != __builtin_signbit(prm.fy));
+  for (int j = 0; j < P; ++j) cxj[j] = static_cast<float>(col0 + j) - prm.cx;
 
-  CellAcc<P, FASTDIV> acc;
+  CellAcc<P, FASTDIV, (P * P <= 256)> acc;
   acc.init();
 
   // group buffers: `cur` holds the 4 rows being processed, `nxt` the 4 rows in flight behind them
@@ -398,14 +423,23 @@ __device__ __forceinline__ void pf_depth_task(Params prm, const PfGroup& grp, dp
   float sum[3], pp[6];
   sum[0] = (acc.sx.c[0] + acc.sx.c[2]) + (acc.sx.c[1] + acc.sx.c[3]);
   sum[1] = (acc.sy.c[0] + acc.sy.c[2]) + (acc.sy.c[1] + acc.sy.c[3]);
-  sum[2] = (acc.sz.c[0] + acc.sz.c[2]) + (acc.sz.c[1] + acc.sz.c[3]);
-  if (FASTDIV && acc.valid_pts == 0) {  // every x and y is a signed zero: restore the IEEE sign of the sums
+  sum[2] = acc.z_sum();
+  const int valid_pts = acc.valid_count();
+  if (FASTDIV && valid_pts == 0) {  // every x and y is a signed zero: restore the IEEE sign of the sums
+    // (a sum of signed zeros is -0 iff every term is -0, i.e. iff (col - cx) * 0 / fx is -0 for every column of the cell;
+    // evaluated here, in the rare branch, rather than carried through the kernel)
+    const int lane_z = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+    bool all_neg_x = true, all_neg_y = true;
+    for (int j = 0; j < P; ++j)
+      all_neg_x = all_neg_x && (__builtin_signbit(static_cast<float>((cc0 + lane_z) * P + j) - prm.cx) != __builtin_signbit(prm.fx));
+    for (int i = 0; i < P; ++i)
+      all_neg_y = all_neg_y && (__builtin_signbit(static_cast<float>(row0 + i) - prm.cy) != __builtin_signbit(prm.fy));
     sum[0] = all_neg_x ? -0.0f : 0.0f;
     sum[1] = all_neg_y ? -0.0f : 0.0f;
   }
   pp[0] = acc.xx; pp[1] = acc.xy; pp[2] = acc.xz; pp[3] = acc.yy; pp[4] = acc.yz; pp[5] = acc.zz;
-  const bool cont = (acc.hdisc < prm.max_disc) && (acc.vdisc < prm.max_disc);
-  const bool valid = prm.valid_thr >= 0 && static_cast<long long>(acc.valid_pts) >= prm.valid_thr && cont;
+  const bool cont = acc.continuous(prm.max_disc);
+  const bool valid = prm.valid_thr >= 0 && static_cast<long long>(valid_pts) >= prm.valid_thr && cont;
 
   dpx_cell rec;
   if (DIAG == 0) {
@@ -426,7 +460,10 @@ __device__ __forceinline__ void pf_depth_task(Params prm, const PfGroup& grp, dp
     rec.normal[0] = acc.fx0 - acc.lx; rec.normal[1] = acc.fy0 - acc.ly; rec.normal[2] = acc.fz0 - acc.lz;
     rec.d = 0.f; rec.mse = 0.f; rec.tol = 0.f; rec.info = valid ? 1u : 0u;
   }
-  float4* dst = reinterpret_cast<float4*>(cells + static_cast<long long>(frame) * prm.C + static_cast<long long>(cr) * prm.nh + cc);
+  // record address = scalar base of the strip + this lane's index, re-derived here (v_mbcnt) instead of being carried
+  // in a vector register pair through the whole kernel
+  const int lane_now = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+  float4* dst = reinterpret_cast<float4*>(cells + static_cast<long long>(frame) * prm.C + static_cast<long long>(cr) * prm.nh + cc0) + 4 * lane_now;
   const float4* s4 = reinterpret_cast<const float4*>(&rec);
   dst[0] = s4[0];
   dst[1] = s4[1];
@@ -517,7 +554,7 @@ __global__ __launch_bounds__(256, 3) void k_planefit_cloud(Params prm, const flo
   sum[1] = (acc.sy.c[0] + acc.sy.c[2]) + (acc.sy.c[1] + acc.sy.c[3]);
   sum[2] = (acc.sz.c[0] + acc.sz.c[2]) + (acc.sz.c[1] + acc.sz.c[3]);
   pp[0] = acc.xx; pp[1] = acc.xy; pp[2] = acc.xz; pp[3] = acc.yy; pp[4] = acc.yz; pp[5] = acc.zz;
-  const bool cont = (acc.hdisc < prm.max_disc) && (acc.vdisc < prm.max_disc);
+  const bool cont = acc.continuous(prm.max_disc);
   const bool valid = prm.valid_thr >= 0 && static_cast<long long>(acc.valid_pts) >= prm.valid_thr && cont;
   dpx_cell rec;
   if (valid) {
@@ -660,7 +697,7 @@ __global__ __launch_bounds__(256, DPX_CLOUD_WAVES) void k_planefit_cloud_lds(Par
   sum[1] = (acc.sy.c[0] + acc.sy.c[2]) + (acc.sy.c[1] + acc.sy.c[3]);
   sum[2] = (acc.sz.c[0] + acc.sz.c[2]) + (acc.sz.c[1] + acc.sz.c[3]);
   pp[0] = acc.xx; pp[1] = acc.xy; pp[2] = acc.xz; pp[3] = acc.yy; pp[4] = acc.yz; pp[5] = acc.zz;
-  const bool cont = (acc.hdisc < prm.max_disc) && (acc.vdisc < prm.max_disc);
+  const bool cont = acc.continuous(prm.max_disc);
   const bool valid = prm.valid_thr >= 0 && static_cast<long long>(acc.valid_pts) >= prm.valid_thr && cont;
   dpx_cell rec;
   if (valid) {
