@@ -564,6 +564,8 @@ __global__ void k_test_math(int which, const double* a, const double* b, double*
     case 1: dpxm::sincos_small(a[i], &s, &c); out[i] = s; break;
     case 2: dpxm::sincos_small(a[i], &s, &c); out[i] = c; break;
     case 3: out[i] = dpxm::dacos(a[i]); break;
+    case 5: out[i] = static_cast<double>(dpx::est_acos(static_cast<float>(a[i]))); break;      // float32 estimates of
+    case 6: out[i] = static_cast<double>(dpx::est_atan2(static_cast<float>(a[i]), static_cast<float>(b[i]))); break;  // finish_cell
     default: out[i] = dpxm::dsqrt(a[i]); break;
   }
 }

@@ -379,6 +379,38 @@ def test_devmath_and_eigensolver_on_device(D, oracle):
     assert nql > 100
 
 
+def test_bin_estimates_stay_inside_their_error_budget(D):
+    """finish_cell decides the histogram bin from float32 estimates of acos / atan2 whenever the scaled angle is at
+    least `margin` away from a bin edge; the margin budgets an absolute estimate error of 1e-6 rad.  Dense sweeps of
+    the device functions against float64."""
+    import ctypes as C
+    from deplex_amd import _capi
+    L = _capi.lib()
+
+    def dev(which, a, b):
+        out = np.zeros(a.size, dtype=np.float64)
+        _capi.check(L.dpx_test_math(which, a.ctypes.data, b.ctypes.data, out.ctypes.data, a.size, 0))
+        return out
+
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.uniform(-1, 1, 2_000_000), np.linspace(-1, 1, 400_001), -1 + np.geomspace(1e-9, 1, 200_000),
+                        1 - np.geomspace(1e-9, 1, 200_000)]).astype(np.float32).astype(np.float64)
+    err = np.abs(dev(5, x, x) - np.arccos(x))
+    assert err.max() < 1e-6, err.max()
+    n = 2_000_000
+    th = rng.uniform(-np.pi, np.pi, n)
+    r = np.exp(rng.uniform(-8, 0, n))
+    yy = (r * np.sin(th)).astype(np.float32).astype(np.float64)
+    xx = (r * np.cos(th)).astype(np.float32).astype(np.float64)
+    yy[:1000] = 0.0  # axes
+    xx[1000:2000] = 0.0
+    keep = (xx != 0) | (yy != 0)
+    e2 = np.abs(dev(6, yy, xx) - np.arctan2(yy, xx))[keep]
+    e2 = np.minimum(e2, np.abs(e2 - 2 * np.pi))  # +pi and -pi are the same direction
+    assert e2.max() < 1e-6, e2.max()
+    assert np.isnan(dev(5, np.array([1.5, np.nan]), np.array([0.0, 0.0]))).all()  # out of range -> NaN -> exact path
+
+
 def test_device_pointer_api_with_torch(D, oracle):
     """The stream-ordered device-pointer entry point fed from torch tensors (device memory + stream plumbing)."""
     import torch
