@@ -15,6 +15,9 @@ for inp in depth cloud; do
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/def -o def -- python3 bench.py --no-cpu-baseline > $out/${tag}_bench_default.json 2>$out/def.err
 cp $(ls $out/def/*kernel_stats.csv $out/def/*/*kernel_stats.csv 2>/dev/null | head -1) $out/${tag}_bench_default_kernel_stats.csv
-python3 tools/trace_summary.py $(ls $out/def/*kernel_trace.csv $out/def/*/*kernel_trace.csv 2>/dev/null | head -1) > $out/${tag}_bench_default_concurrency.txt
+python3 tools/trace_streams.py $(ls $out/def/*kernel_trace.csv $out/def/*/*kernel_trace.csv 2>/dev/null | head -1) > $out/${tag}_bench_default_concurrency.txt
+python3 tools/make_traffic_json.py $tag $out/${tag}_pmc_depth_FETCH_SIZE.txt $out/${tag}_pmc_depth_WRITE_SIZE.txt $out/${tag}_pmc_cloud_FETCH_SIZE.txt $out/${tag}_pmc_cloud_WRITE_SIZE.txt $out/${tag}_roofline_only_depth_bench.json $out/${tag}_roofline_only_cloud_bench.json > $out/planefit_traffic.json
+# the driver's own protocol (20 timed steps after 5 warm-up steps)
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/${tag}_bench_steps20.json 2>>$out/def.err
 rm -rf $out/ro_* $out/pmc_*_*SIZE $out/def
 ls -la $out

@@ -7,6 +7,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 def kind(n):
     m = re.search(r'k_regions2<\w+, \w+, (\d)>', n) or re.search(r'k_regions2ILi\dELb\dELi(\d)E', n)
     if 'planefit' in n: return 'pf'
+    if 'region_prep' in n: return 'reg1'
     if 'regions' in n: return 'reg' + (m.group(1) if m else '')
     if 'labels' in n: return 'lab'
     return None

@@ -5,7 +5,7 @@ ev = []
 for r in rows:
     n = r['Kernel_Name']
     m = re.search(r'k_regions2<\w+, \w+, (\d)>', n) or re.search(r'k_regions2ILb\dELb\dELi(\d)E', n)
-    k = 'pf' if 'planefit' in n else ('reg' + (m.group(1) if m else '')) if 'regions' in n else 'lab' if 'labels' in n else 'sort' if 'k_sort' in n else 'graph' if 'cellgraph' in n else None
+    k = 'pf' if 'planefit' in n else 'reg1' if 'region_prep' in n else ('reg' + (m.group(1) if m else '')) if 'regions' in n else 'lab' if 'labels' in n else 'sort' if 'k_sort' in n else 'graph' if 'cellgraph' in n else None
     if k: ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), k))
 ev.sort()
 s = ev[len(ev) // 4][0]; e = ev[3 * len(ev) // 4][1]

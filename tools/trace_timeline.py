@@ -6,6 +6,7 @@ npf = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 def short(n):
     m = re.search(r'k_regions2<\w+, \w+, (\d)>', n) or re.search(r'k_regions2ILi\dELb\dELi(\d)E', n)
     if 'planefit' in n: return 'pf'
+    if 'region_prep' in n: return 'reg1'
     if 'regions' in n: return 'reg' + (m.group(1) if m else '')
     if 'labels' in n: return 'lab'
     return n[:24]
