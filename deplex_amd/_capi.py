@@ -90,6 +90,8 @@ SYMBOLS = {
     "dpx_time_planefit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.POINTER(C.c_float)]),
     "dpx_time_planefit_group": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.POINTER(C.c_float)]),
     "dpx_planefit_bytes": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32]),
+    "dpx_read_depth_png": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_uint16))]),
+    "dpx_free": (None, [C.c_void_p]),
     "dpx_debug_residency": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "dpx_debug_trace": (C.c_int, [C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "dpx_test_math": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),

@@ -13,10 +13,11 @@ OUT = PKG / "lib" / "libdeplex_amd.so"
 # before the following add for results to be bit-identical.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
          "-Wno-unused-value", "-Wno-pass-failed"]
+LIBS = ["-lz"]  # the PNG reader of the DepthImage path constructor (dpx_png.h) inflates with zlib
 
 
 def sources():
-    return [SRC / "dpx_api.hip", SRC / "dpx_kernels.h", SRC / "dpx_regions.h", SRC / "dpx_regions2.h", SRC / "dpx_binsort.h", SRC / "dpx_refine.h", SRC / "dpx_planefit_fast.h", SRC / "dpx_fit.h", SRC / "dpx_math.h",
+    return [SRC / "dpx_api.hip", SRC / "dpx_kernels.h", SRC / "dpx_regions.h", SRC / "dpx_regions2.h", SRC / "dpx_binsort.h", SRC / "dpx_refine.h", SRC / "dpx_planefit_fast.h", SRC / "dpx_fit.h", SRC / "dpx_math.h", SRC / "dpx_png.h",
             PKG.parent / "include" / "deplex_amd.h"]
 
 
@@ -33,7 +34,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     OUT.parent.mkdir(parents=True, exist_ok=True)
     tmp = OUT.with_suffix(".so.tmp")
-    cmd = [hipcc, *FLAGS, str(SRC / "dpx_api.hip"), "-o", str(tmp)]
+    cmd = [hipcc, *FLAGS, str(SRC / "dpx_api.hip"), "-o", str(tmp), *LIBS]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
@@ -51,7 +52,7 @@ def build_variant(name: str, defines=(), force: bool = False) -> Path:
         return out
     out.parent.mkdir(parents=True, exist_ok=True)
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    subprocess.run([hipcc, *FLAGS, *[f"-D{d}" for d in defines], str(SRC / "dpx_api.hip"), "-o", str(out)], check=True)
+    subprocess.run([hipcc, *FLAGS, *[f"-D{d}" for d in defines], str(SRC / "dpx_api.hip"), "-o", str(out), *LIBS], check=True)
     return out
 
 

@@ -1,7 +1,9 @@
 // deplex/utils/depth_image.h — C++ mirror of deplex::utils::DepthImage (cpp/deplex/include/deplex/utils/depth_image.h:24-56).
 // The back-projection arithmetic (utils/depth_image.cpp:55-78) runs in the HIP kernel behind dpx_backproject.
-// PNG decoding is file IO and outside the accelerated path (the reference vendors stb_image for it): this mirror is
-// constructed from a decoded 16-bit buffer; readIntrinsics mirrors utils/eigen_io.cpp:41-55.
+// PNG decoding is file IO and outside the accelerated path (the reference vendors stb_image for it): the path
+// constructor goes through the library's reader (dpx_read_depth_png, same conversion rules as the reference's
+// stbi_load_16(..., STBI_grey) call); a decoded 16-bit buffer can be passed directly as well.  readIntrinsics mirrors
+// utils/eigen_io.cpp:41-55.
 #pragma once
 #include <array>
 #include <cstdint>
@@ -28,7 +30,19 @@ inline Intrinsics readIntrinsics(std::string const& intrinsics_path) {
 class DepthImage {
  public:
   DepthImage() : width_(0), height_(0) {}
+  /** The reference's constructor (utils/depth_image.cpp:27-41): reads a PNG as one 16-bit grey channel. */
+  explicit DepthImage(std::string const& image_path) : width_(0), height_(0) { reset(image_path); }
   DepthImage(uint16_t const* data, int32_t height, int32_t width) : image_(data, data + static_cast<size_t>(height) * width), width_(width), height_(height) {}
+  /** utils/depth_image.cpp:43-50; throws std::runtime_error("Error: Couldn't read image <path>") like the reference. */
+  void reset(std::string const& image_path) {
+    uint16_t* data = nullptr;
+    int32_t h = 0, w = 0;
+    if (dpx_read_depth_png(image_path.c_str(), &h, &w, &data) != DPX_OK) throw std::runtime_error(dpx_last_error());
+    image_.assign(data, data + static_cast<size_t>(h) * w);
+    dpx_free(data);
+    width_ = w;
+    height_ = h;
+  }
   int32_t getWidth() const { return width_; }
   int32_t getHeight() const { return height_; }
   uint16_t const* data() const { return image_.data(); }

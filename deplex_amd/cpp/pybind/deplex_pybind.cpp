@@ -23,17 +23,11 @@ namespace {
 
 using FloatArray = py::array_t<float, py::array::c_style | py::array::forcecast>;
 
-// utils::DepthImage with the reference's path constructor (depth_image.cpp:27-53: 16-bit single-channel PNG)
+// utils::DepthImage with the reference's path constructor (depth_image.cpp:27-53), decoded by the library (dpx_read_depth_png)
 class PyDepthImage {
  public:
   explicit PyDepthImage(std::string const& image_path) { reset(image_path); }
-  void reset(std::string const& image_path) {
-    py::object img = py::module_::import("PIL.Image").attr("open")(image_path);
-    py::array_t<uint16_t, py::array::c_style | py::array::forcecast> a =
-        py::module_::import("numpy").attr("asarray")(img, py::arg("dtype") = "uint16");
-    if (a.ndim() != 2) throw std::runtime_error("Error: depth image must have one 16-bit channel: " + image_path);
-    image_ = deplex::utils::DepthImage(a.data(), static_cast<int32_t>(a.shape(0)), static_cast<int32_t>(a.shape(1)));
-  }
+  void reset(std::string const& image_path) { image_.reset(image_path); }
   int32_t height() const { return image_.getHeight(); }
   int32_t width() const { return image_.getWidth(); }
   // Eigen::MatrixXf toPointCloud(Eigen::Matrix3f const&) -> (N, 3) float32 (depth_image.cpp:55-78)

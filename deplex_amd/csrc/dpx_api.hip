@@ -18,6 +18,7 @@
 #include "dpx_regions2.h"
 #include "dpx_binsort.h"
 #include "dpx_refine.h"
+#include "dpx_png.h"
 
 namespace {
 
@@ -932,6 +933,24 @@ int dpx_backproject(const uint16_t* depth, int32_t height, int32_t width, float 
   if (e != hipSuccess) return fail(DPX_ERR_HIP, hipGetErrorString(e));
   return DPX_OK;
 }
+
+int dpx_read_depth_png(const char* path, int32_t* height, int32_t* width, uint16_t** data) {
+  if (!path || !height || !width || !data) return fail(DPX_ERR_ARG, "null argument");
+  *data = nullptr;
+  dpxpng::Image img;
+  const std::string err = dpxpng::read_grey16(path, img);
+  if (!err.empty()) return fail(DPX_ERR_IO, std::string("Error: Couldn't read image ") + path);  // depth_image.cpp:33
+  const size_t n = static_cast<size_t>(img.width) * img.height;
+  uint16_t* buf = static_cast<uint16_t*>(std::malloc(std::max<size_t>(n, 1) * sizeof(uint16_t)));
+  if (!buf) return fail(DPX_ERR_IO, "out of memory");
+  std::memcpy(buf, img.grey.data(), n * sizeof(uint16_t));
+  *height = img.height;
+  *width = img.width;
+  *data = buf;
+  return DPX_OK;
+}
+
+void dpx_free(void* p) { std::free(p); }
 
 int dpx_grid_dims(dpx_handle h, int32_t* nh, int32_t* nv) {
   if (!h) return fail(DPX_ERR_ARG, "null handle");

@@ -1,8 +1,8 @@
 """Python mirror of the reference's `deplex.utils` (cpp/pybind/utils/utils.cpp:29-36):
 DepthImage(image_path), .height, .width, .transform_to_pcd(intrinsics), .reset(image_path).
 
-PNG decoding is file IO (the reference uses stb_image, utils/depth_image.cpp:30-40) and is done with Pillow on
-the host; the back-projection arithmetic (depth_image.cpp:55-78) runs in the HIP kernel behind dpx_backproject.
+PNG decoding is file IO (the reference uses stb_image, utils/depth_image.cpp:30-40): the library's own host-side reader
+(csrc/dpx_png.h, zlib for the inflation) with stb's conversion rules; the back-projection arithmetic (depth_image.cpp:55-78) runs in the HIP kernel behind dpx_backproject.
 """
 from __future__ import annotations
 
@@ -22,17 +22,17 @@ def read_intrinsics(path) -> np.ndarray:
 
 
 def _load_u16(path) -> np.ndarray:
+    """PNG file -> (H, W) uint16 through the library's reader, which applies the conversion rules of the reference's
+    stbi_load_16(path, ..., STBI_grey) (utils/depth_image.cpp:30-40): colour -> luma, alpha dropped, 8-bit data * 257."""
+    import ctypes as C
+    h, w = C.c_int32(), C.c_int32()
+    data = C.POINTER(C.c_uint16)()
+    _capi.check(_capi.lib().dpx_read_depth_png(str(path).encode(), C.byref(h), C.byref(w), C.byref(data)))
     try:
-        from PIL import Image
-        with Image.open(path) as im:
-            if im.format != "PNG":
-                raise ValueError("not a PNG")  # the reference is built with STBI_ONLY_PNG
-            arr = np.array(im)
-    except Exception:
-        raise _capi.DeplexError(_capi.DPX_ERR_IO, f"Error: Couldn't read image {path}")
-    if arr.ndim == 3:  # stbi_load_16(..., STBI_grey) converts colour to grey; depth maps are single channel
-        arr = arr[..., 0]
-    return np.ascontiguousarray(arr.astype(np.uint16))
+        arr = np.ctypeslib.as_array(data, shape=(h.value, w.value)).copy()
+    finally:
+        _capi.lib().dpx_free(data)
+    return arr
 
 
 class DepthImage:

@@ -159,6 +159,13 @@ dpx_handle dpx_pipeline_slot(dpx_pipeline p, int32_t slot);
  * receives 1 if the fast sequence is exact for these intrinsics, 0 if the kernel will use IEEE division. */
 int dpx_prepare_intrinsics(dpx_handle h, float fx, float fy, float cx, float cy, int32_t* fast_division);
 
+/* DepthImage::DepthImage(path) / reset(path) — utils/depth_image.cpp:27-53: decodes a PNG (host file IO) to ONE 16-bit
+ * grey channel with the conversion rules of the reference's stbi_load_16(..., STBI_grey) call (colour -> luma, alpha
+ * dropped, palette expanded, 8-bit data widened as v * 257).  *data is allocated by the library (height * width
+ * values, row-major); release it with dpx_free.  DPX_ERR_IO with the reference's message if the file cannot be read. */
+int dpx_read_depth_png(const char* path, int32_t* height, int32_t* width, uint16_t** data);
+void dpx_free(void* p);
+
 /* DepthImage::toPointCloud — utils/depth_image.cpp:55-78: depth H x W uint16 (HOST) -> xyz N x 3 float32 (HOST). */
 int dpx_backproject(const uint16_t* depth, int32_t height, int32_t width, float fx, float fy, float cx, float cy,
                     float* xyz, int32_t device);

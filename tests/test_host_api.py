@@ -3,6 +3,7 @@ Config mirrors the reference's defaults and .ini reader, and the product fails l
 import re
 from pathlib import Path
 
+import numpy as np
 import pytest
 
 import synth
@@ -162,3 +163,100 @@ def test_pybind_surface_matches_reference():
     assert (img.height, img.width) == (480, 640)
     img.reset(str(synth.ICL_PNG))
     assert (img.height, img.width) == (480, 640)
+
+
+def _stb_grey16(arr, mode):
+    """What stbi_load_16(path, ..., STBI_grey) returns for an image with these samples (utils/depth_image.cpp:30-40):
+    an 8-bit file is reduced to one grey channel in 8 bits ((77 r + 150 g + 29 b) >> 8, alpha dropped) and then widened
+    to 16 bits as v * 257; a 16-bit file is reduced in 16 bits."""
+    a = np.asarray(arr).astype(np.uint32)
+    if mode in ("RGB", "RGBA"):
+        y = (a[..., 0] * 77 + a[..., 1] * 150 + a[..., 2] * 29) >> 8
+    elif mode == "LA":
+        y = a[..., 0]
+    else:
+        y = a
+    return (y * 257).astype(np.uint16)
+
+
+def test_png_reader_follows_the_reference_loader(tmp_path):
+    """DepthImage(path) decodes through the library's own PNG reader (csrc/dpx_png.h) with the conversion rules of the
+    reference's stb_image call: 16-bit grey (the depth-map format), 8-bit grey, grey + alpha, RGB, RGBA, palette,
+    1-bit, 16-bit RGB written by hand, and Adam7 interlacing."""
+    import struct, zlib
+    from PIL import Image
+    from deplex_amd import utils
+    rng = np.random.default_rng(3)
+    h, w = 37, 53  # odd sizes: exercises partial bytes and every Adam7 pass boundary
+    # the reference's own fixture (16-bit grey): identical to Pillow's decoding, max 46655 (cpp/tests/test_depth_image.cpp:42-48)
+    tum = utils._load_u16(synth.TUM_PNG)
+    assert tum.shape == (480, 640) and np.array_equal(tum, synth.load_png_u16(synth.TUM_PNG)) and tum.max() == 46655 and tum.min() == 0
+    g16 = rng.integers(0, 65536, size=(h, w), dtype=np.uint16)
+    Image.fromarray(g16).save(tmp_path / "g16.png")
+    assert np.array_equal(utils._load_u16(tmp_path / "g16.png"), g16)
+    for mode, ch in (("L", 1), ("LA", 2), ("RGB", 3), ("RGBA", 4)):
+        a = rng.integers(0, 256, size=(h, w, ch) if ch > 1 else (h, w), dtype=np.uint8)
+        Image.fromarray(a, mode).save(tmp_path / f"{mode}.png")
+        assert np.array_equal(utils._load_u16(tmp_path / f"{mode}.png"), _stb_grey16(a, mode)), mode
+    # palette image: indices through the palette, then luma
+    idx = rng.integers(0, 200, size=(h, w), dtype=np.uint8)
+    pal = rng.integers(0, 256, size=(256, 3), dtype=np.uint8)
+    im = Image.fromarray(idx, "P"); im.putpalette(pal.reshape(-1).tolist()); im.save(tmp_path / "p.png")
+    assert np.array_equal(utils._load_u16(tmp_path / "p.png"), _stb_grey16(pal[idx], "RGB"))
+    # 1-bit grey: 0 / 255, then * 257
+    bits = rng.integers(0, 2, size=(h, w), dtype=np.uint8)
+    Image.fromarray(bits * 255).convert("1").save(tmp_path / "b1.png")
+    assert np.array_equal(utils._load_u16(tmp_path / "b1.png"), (bits.astype(np.uint16) * 65535))
+
+    def write_png(path, width, height, depth, ctype, rows, interlace=0):
+        def chunk(t, d): return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+        raw = b"".join(rows)
+        path.write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, depth, ctype, 0, 0, interlace)) +
+                         chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+    # 16-bit RGB (Pillow cannot write it): big-endian samples, luma in 16 bits; filter types 0..4 in turn
+    c16 = rng.integers(0, 65536, size=(h, w, 3), dtype=np.uint16)
+    def filtered(rowbytes, prev, ft, bpp):
+        cur = np.frombuffer(rowbytes, dtype=np.uint8).astype(np.int32)
+        up = np.frombuffer(prev, dtype=np.uint8).astype(np.int32) if prev is not None else np.zeros_like(cur)
+        out = np.zeros_like(cur)
+        for i in range(len(cur)):
+            a = cur[i - bpp] if i >= bpp else 0
+            b = up[i]
+            c = up[i - bpp] if i >= bpp else 0
+            if ft == 0: pred = 0
+            elif ft == 1: pred = a
+            elif ft == 2: pred = b
+            elif ft == 3: pred = (a + b) >> 1
+            else:
+                p = a + b - c; pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            out[i] = (cur[i] - pred) & 0xFF
+        return bytes([ft]) + out.astype(np.uint8).tobytes()
+    rows, prev = [], None
+    for r in range(h):
+        rb = c16[r].astype(">u2").tobytes()
+        rows.append(filtered(rb, prev, r % 5, 6))
+        prev = rb
+    write_png(tmp_path / "rgb16.png", w, h, 16, 2, rows)
+    exp = ((c16[..., 0].astype(np.uint32) * 77 + c16[..., 1].astype(np.uint32) * 150 + c16[..., 2].astype(np.uint32) * 29) >> 8).astype(np.uint16)
+    assert np.array_equal(utils._load_u16(tmp_path / "rgb16.png"), exp)
+    # Adam7-interlaced 16-bit grey
+    passes = [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]
+    rows = []
+    for x0, y0, dx, dy in passes:
+        sub = g16[y0::dy, x0::dx]
+        if sub.size == 0:
+            continue
+        for r in range(sub.shape[0]):
+            rows.append(b"\x00" + sub[r].astype(">u2").tobytes())
+    write_png(tmp_path / "adam7.png", w, h, 16, 0, rows, interlace=1)
+    assert np.array_equal(utils._load_u16(tmp_path / "adam7.png"), g16)
+    # failures carry the reference's message (utils/depth_image.cpp:33)
+    from deplex_amd._capi import DeplexError
+    for bad in (synth.GOLDEN / "invalid" / "MissingParameters.ini", tmp_path / "does_not_exist.png"):
+        with pytest.raises(DeplexError, match="Error: Couldn't read image"):
+            utils._load_u16(bad)
+    (tmp_path / "trunc.png").write_bytes((tmp_path / "g16.png").read_bytes()[:200])
+    with pytest.raises(DeplexError, match="Error: Couldn't read image"):
+        utils._load_u16(tmp_path / "trunc.png")
