@@ -19,6 +19,10 @@
 
 namespace dpx {
 
+// operand types of the gfx950 LDS-DMA loads (__builtin_amdgcn_global_load_lds)
+typedef __attribute__((address_space(3))) void* dpx_lds_ptr;
+typedef const __attribute__((address_space(1))) void* dpx_glb_ptr;
+
 // ---- diagnostic wave trace (dpx_debug_trace): every wave of the pipeline's kernels logs where and when it ran --------
 // Entry = 4 x u64: start and end in 100 MHz real-time ticks (s_memrealtime: one clock for the whole chip), the hardware
 // id (XCC << 32 | HW_ID: SE, CU, SIMD, wave slot), and kind | wave-in-block << 4 | blockIdx.x << 8.  A hardware wave slot

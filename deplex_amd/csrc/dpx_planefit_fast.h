@@ -587,8 +587,6 @@ __global__ __launch_bounds__(256, 3) void k_planefit_cloud(Params prm, const flo
 #ifndef DPX_CLOUD_WAVES
 #define DPX_CLOUD_WAVES 2
 #endif
-typedef __attribute__((address_space(3))) void* dpx_lds_ptr;
-typedef const __attribute__((address_space(1))) void* dpx_glb_ptr;
 
 template <int P>
 struct CloudStage {

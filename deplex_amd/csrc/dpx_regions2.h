@@ -204,8 +204,16 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
   float4* lds_v = reinterpret_cast<float4*>(smem);
   float4* img = rx.lds_img + static_cast<size_t>(frame) * (rx.img_bytes >> 4);
   const int img_vec = rx.img_bytes >> 4;
-  if (PHASE >= 2) {  // continue from the previous launch's LDS image
-    for (int i = tid; i < img_vec; i += static_cast<int>(blockDim.x)) lds_v[i] = img[i];
+  if (PHASE >= 2) {
+    // continue from the previous launch's LDS image: gfx950 LDS-DMA (global_load_lds_dwordx4: lane l of a wave delivers
+    // bytes [16 l, 16 l + 16) of a 1 KB chunk straight into LDS, no staging registers).  All chunks of a wave are in
+    // flight together and awaited once — the plain copy loop compiles to load, wait, store per KB, i.e. 32 serialized
+    // memory round trips in front of the one-wave grow launch.
+    const int nthreads = static_cast<int>(blockDim.x);
+    for (int base = tid - lane; base < img_vec; base += nthreads)  // (tid - lane: first vector of this wave's chunk)
+      if (base + lane < img_vec)
+        __builtin_amdgcn_global_load_lds((dpx_glb_ptr)(img + base + lane), (dpx_lds_ptr)(lds_v + base), 16, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     __syncthreads();
   }
   if (PHASE <= 1) {
