@@ -777,7 +777,7 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
   A(dev_alloc(&h->d_merge, B * h->pcap));
   A(dev_alloc(&h->d_stats, B));
   A(dev_alloc(&h->d_mse_c, B * C));
-  A(dev_alloc(&h->d_cand_grow, B * h->pcap));
+  A(dev_alloc(&h->d_cand_grow, B * h->pcap * 4));
   if (!h->use_lds && h->regions_tier < 0) {
     A(dev_alloc(&h->d_gflags, B * C));
     A(dev_alloc(&h->d_gowner, B * C));

@@ -113,7 +113,7 @@ __host__ __device__ inline R2Layout r2_layout(int tier, int C, int nb, int nh) {
 
 struct Regions2Extra {
   const float* mse_c;   // [B][C] compact per-cell mse (k_cellgraph output; read by dpx_binsort.h, not by k_regions2)
-  uint32_t* cand_grow;  // [B][pcap] grow index of each candidate segment
+  uint32_t* cand_grow;  // [B][pcap][4] per candidate segment: grow index, first and one-past-last queue position, unused
   unsigned long long* dbg;  // diagnostic build only: [B][16] shader-clock stamps / sums
   float4* lds_img;          // split mode: [B][img_bytes] image of the workgroup's LDS handed from phase to phase
   int img_bytes;            // multiple of 16
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
   const dpx_cell* cells = rb.cells + static_cast<size_t>(frame) * C;
   const uint32_t* meta = rb.meta + static_cast<size_t>(frame) * C;
   uint32_t* grow_start = rb.grow_start + static_cast<size_t>(frame) * (C + 1);
-  uint32_t* cand_grow = rx.cand_grow + static_cast<size_t>(frame) * rb.pcap;
+  uint4* cand_grow = reinterpret_cast<uint4*>(rx.cand_grow) + static_cast<size_t>(frame) * rb.pcap;
   float* cand = rb.cand + static_cast<size_t>(frame) * rb.pcap * 12;
   dpx_plane* planes = rb.planes + static_cast<size_t>(frame) * rb.pcap;
   int32_t* cell_labels = rb.cell_labels + static_cast<size_t>(frame) * C;
@@ -411,7 +411,8 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
                            ncand < rb.pcap;
       if (lane == 0) {
         grow_start[ngrow] = static_cast<uint32_t>(gstart);
-        if (is_cand) cand_grow[ncand] = static_cast<uint32_t>(ngrow);
+        // (the tail reads the segment's queue range from here with one load instead of chasing grow_start twice)
+        if (is_cand) cand_grow[ncand] = make_uint4(static_cast<uint32_t>(ngrow), static_cast<uint32_t>(gstart), static_cast<uint32_t>(tail), 0u);
       }
       ncand += is_cand;
       ++ngrow;
@@ -698,8 +699,8 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
     float* st = stage + wid * kStage * 9;
     const float4* cf4 = reinterpret_cast<const float4*>(cells);
     for (int ci = wid; ci < ncand; ci += kRW) {
-      const int gi = static_cast<int>(cand_grow[ci]);
-      const int gs = static_cast<int>(grow_start[gi]), ge = static_cast<int>(grow_start[gi + 1]);
+      const uint4 cg = cand_grow[ci];
+      const int gi = static_cast<int>(cg.x), gs = static_cast<int>(cg.y), ge = static_cast<int>(cg.z);
       const int comp = lane < 9 ? lane : 0;
       float acc = reinterpret_cast<const float*>(cells)[static_cast<size_t>(queue[gs]) * 16 + comp];  // the seed, counted twice
       // the records of the NEXT 32 cells are fetched while the 9 chains run over the current 32 (the chains are
@@ -787,7 +788,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
       pl.normal[0] = fit.normal[0]; pl.normal[1] = fit.normal[1]; pl.normal[2] = fit.normal[2];
       pl.d = fit.d; pl.mse = fit.mse; pl.score = fit.score;
       pl.n_pts = npts;
-      pl.n_cells = static_cast<int>(grow_start[gi + 1] - grow_start[gi]);
+      pl.n_cells = static_cast<int>(cand_grow[ci].z - cand_grow[ci].y);
       pl.merge_label = id;
       merge[id] = id;
     }
@@ -802,8 +803,8 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
     const float* co = cand + static_cast<size_t>(ci) * 12;
     const int id1 = __float_as_int(co[11]);
     if (id1 == 0) continue;
-    const int gi = __float_as_int(co[10]);
-    const int gs = static_cast<int>(grow_start[gi]), ge = static_cast<int>(grow_start[gi + 1]);
+    const uint4 cg = cand_grow[ci];
+    const int gs = static_cast<int>(cg.y), ge = static_cast<int>(cg.z);
     for (int i = gs + lane; i < ge; i += 64) lab16[queue[i]] = static_cast<idx_t>(id1);
   }
   __syncthreads();
