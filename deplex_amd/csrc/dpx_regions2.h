@@ -833,10 +833,41 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
   // walk does not need the workgroup (no CSR build, no fused label expansion), waves 1.. end here and give their
   // registers and wave slots back to the chip; wave 0 finishes the frame alone, without further workgroup barriers.
   const bool solo = !DBG && !rx.labels_out[0] && (nplanes == 0 || fast);
-  if (solo && wid != 0) return;
-  const int tstride = solo ? 64 : kRT;
   const int gw = nh - 1, gh = nv - 1;
   const int gtotal = gw > 0 && gh > 0 ? gw * gh : 0;
+  uint32_t* mat = reinterpret_cast<uint32_t*>(stage);
+  float* pview = GST ? reinterpret_cast<float*>(smem + pv_off) : reinterpret_cast<float*>(qpos);  // dead arrays
+  int32_t* lmerge = reinterpret_cast<int32_t*>(pview + 7 * nplanes);
+  if (nplanes > 0 && fast) {
+    // adjacency bit matrix and plane views: the whole workgroup builds them (a scan of the cell grid), before waves 1..
+    // leave
+    for (int w = tid; w < nplanes * wpr; w += kRT) mat[w] = 0;
+    for (int i = tid; i < nplanes; i += kRT) {
+      const dpx_plane& pl = planes[i];
+      float* pv = pview + i * 7;
+      pv[0] = pl.normal[0]; pv[1] = pl.normal[1]; pv[2] = pl.normal[2]; pv[3] = pl.d;
+      pv[4] = pl.mean[0]; pv[5] = pl.mean[1]; pv[6] = pl.mean[2];
+      lmerge[i] = i;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < gtotal; idx += kRT) {
+      const int r = idx / gw, c = idx - r * gw;
+      const int a = lab16[r * nh + c];
+      const int right = lab16[r * nh + c + 1];
+      const int down = lab16[(r + 1) * nh + c];
+      if (a > 0 && right > 0 && a != right) {
+        atomicOr(&mat[(a - 1) * wpr + ((right - 1) >> 5)], 1u << ((right - 1) & 31));
+        atomicOr(&mat[(right - 1) * wpr + ((a - 1) >> 5)], 1u << ((a - 1) & 31));
+      }
+      if (a > 0 && down > 0 && a != down) {
+        atomicOr(&mat[(a - 1) * wpr + ((down - 1) >> 5)], 1u << ((down - 1) & 31));
+        atomicOr(&mat[(down - 1) * wpr + ((a - 1) >> 5)], 1u << ((a - 1) & 31));
+      }
+    }
+    __syncthreads();
+  }
+  if (solo && wid != 0) return;
+  const int tstride = solo ? 64 : kRT;
   // merge test of the row plane (pnx.., pd) against a column plane (plane_extractor.cpp:405-412)
   auto merge_test = [&](float pnx, float pny, float pnz, float pd, float cnx, float cny, float cnz, float cmx, float cmy, float cmz) {
     const float cosv = dot3(pnx, pny, pnz, cnx, cny, cnz);
@@ -845,37 +876,6 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
     return static_cast<double>(cosv) > static_cast<double>(prm.min_cos) && dist < static_cast<double>(prm.max_merge_dist);
   };
   if (nplanes > 0 && fast && wid == 0) {
-    uint32_t* mat = reinterpret_cast<uint32_t*>(stage);
-    float* pview = GST ? reinterpret_cast<float*>(smem + pv_off) : reinterpret_cast<float*>(qpos);  // dead arrays
-    int32_t* lmerge = reinterpret_cast<int32_t*>(pview + 7 * nplanes);
-    for (int w = lane; w < nplanes * wpr; w += 64) mat[w] = 0;
-    for (int i = lane; i < nplanes; i += 64) {
-      const dpx_plane& pl = planes[i];
-      float* pv = pview + i * 7;
-      pv[0] = pl.normal[0]; pv[1] = pl.normal[1]; pv[2] = pl.normal[2]; pv[3] = pl.d;
-      pv[4] = pl.mean[0]; pv[5] = pl.mean[1]; pv[6] = pl.mean[2];
-      lmerge[i] = i;
-    }
-    wave_sync();
-    for (int base = 0; base < gtotal; base += 64) {
-      const int idx = base + lane;
-      if (idx < gtotal) {
-        const int r = idx / gw, c = idx - r * gw;
-        const int a = lab16[r * nh + c];
-        const int right = lab16[r * nh + c + 1];
-        const int down = lab16[(r + 1) * nh + c];
-        if (a > 0 && right > 0 && a != right) {
-          atomicOr(&mat[(a - 1) * wpr + ((right - 1) >> 5)], 1u << ((right - 1) & 31));
-          atomicOr(&mat[(right - 1) * wpr + ((a - 1) >> 5)], 1u << ((a - 1) & 31));
-        }
-        if (a > 0 && down > 0 && a != down) {
-          atomicOr(&mat[(a - 1) * wpr + ((down - 1) >> 5)], 1u << ((down - 1) & 31));
-          atomicOr(&mat[(down - 1) * wpr + ((a - 1) >> 5)], 1u << ((a - 1) & 31));
-        }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    wave_sync();
     for (int row = 0; row < nplanes; ++row) {
       const uint32_t* rowbits = mat + row * wpr;
       const int pid = lmerge[row];
