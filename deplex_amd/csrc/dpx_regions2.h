@@ -1067,14 +1067,17 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
   if (!solo) __syncthreads();
   t_p5 = DPX_STAMP();
   // ---------------- P6: merged label per cell (toImageLabels' lookup, plane_extractor.cpp:464-465); records --------
+  // (merge labels from their LDS copy where the merge ran on the bit matrix: one wave walks all cells here, and a
+  // global gather per iteration would be a serialized memory round trip each)
+  const bool lds_merge = nplanes > 0 && fast;
   for (int c = tid; c < C; c += tstride) {
     const int L = lab16[c];
-    const int fin = (L == 0 || nplanes == 0) ? 0 : merge[L - 1] + 1;
+    const int fin = (L == 0 || nplanes == 0) ? 0 : (lds_merge ? lmerge[L - 1] : merge[L - 1]) + 1;
     cell_labels[c] = fin;
     lab16[c] = static_cast<idx_t>(fin);  // final labels stay in LDS for the fused expansion below
   }
   if (nplanes > 0)
-    for (int i = tid; i < nplanes; i += tstride) planes[i].merge_label = merge[i];
+    for (int i = tid; i < nplanes; i += tstride) planes[i].merge_label = lds_merge ? lmerge[i] : merge[i];
   if (rx.labels_out[0]) {
     // Fused toImageLabels (plane_extractor.cpp:455-470), W % 4 == 0: this workgroup writes its frame's label map with
     // 16-byte stores straight from the LDS-resident cell labels.  Done here (on the few CUs that run region growing,
