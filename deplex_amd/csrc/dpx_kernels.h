@@ -555,9 +555,8 @@ struct LabelOuts {
   int32_t* out[8];
   int per_out;
 };
-// Block b takes the (frame, cell row) tasks b, b + gridDim.x, ...: one block per task by default, a bounded persistent
-// grid with DPX_LAB_RESIDENT=n (an experiment: label blocks filling every wave slot of the chip turned out not to be
-// what keeps the other groups' kernels from overlapping with this one).
+// Block b takes the (frame, cell row) tasks b, b + gridDim.x, ...: the host starts one block per CU (a few dozen blocks
+// already write at the full HBM rate; DPX_LAB_RESIDENT=0 gives one block per task).
 __global__ __launch_bounds__(256) void k_labels_rows(Params prm, const int32_t* __restrict__ cell_labels, LabelOuts outs, int rows_per_frame) {
  WaveTrace trace_(TK_LABELS);
  const int ntasks = prm.batch * rows_per_frame;
