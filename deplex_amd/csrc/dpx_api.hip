@@ -1205,7 +1205,9 @@ int dpx_set_profiling(dpx_handle h, int32_t enable) {
   DPX_HIP(hipSetDevice(h->device));
   if (enable && !h->ev_created) {
     for (auto& slot : h->ev)
-      for (auto& e : slot) DPX_HIP(hipEventCreate(&e));
+      // (no system-scope fence when the event is recorded: a fence writes back and invalidates the caches under every
+      // kernel on the chip, and these events only time launches)
+      for (auto& e : slot) DPX_HIP(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
     h->ev_created = true;
   }
   h->profiling = enable != 0;
