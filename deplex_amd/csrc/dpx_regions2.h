@@ -876,7 +876,24 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
     return static_cast<double>(cosv) > static_cast<double>(prm.min_cos) && dist < static_cast<double>(prm.max_merge_dist);
   };
   if (nplanes > 0 && fast && wid == 0) {
-    for (int row = 0; row < nplanes; ++row) {
+    // rows in ascending order; a row whose plane has no adjacent plane with a larger id does nothing and is skipped (the
+    // bit matrix does not change during the walk)
+    for (int rbase = 0; rbase < nplanes; rbase += 64) {
+     unsigned long long todo;
+     {
+       const int rr = rbase + lane;
+       bool any = false;
+       if (rr < nplanes)
+         for (int w = rr >> 5; w < wpr; ++w) {
+           uint32_t bits = mat[rr * wpr + w];
+           if (w == (rr >> 5)) bits &= ~((2u << (rr & 31)) - 1u);  // columns above rr only
+           any = any || bits != 0u;
+         }
+       todo = __ballot(any);
+     }
+     while (todo) {
+      const int row = rbase + static_cast<int>(__builtin_ctzll(todo));
+      todo &= todo - 1;
       const uint32_t* rowbits = mat + row * wpr;
       const int pid = lmerge[row];
       const float* pv = pview + pid * 7;
@@ -923,6 +940,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : kRT) void k_regions2(Params prm, 
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       }
       wave_sync();
+     }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   }
