@@ -3,10 +3,13 @@ Prints time-averaged occupancy per SIMD / CU by kernel kind: resident waves, VGP
 could have taken another workgroup of each kind.   usage: python tools/wave_trace.py [steps] [DPX_SKIP letters]"""
 import os, sys, ctypes as C
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+import subprocess
 from pathlib import Path as _P
-sys.path.insert(0, str(_P(__file__).resolve().parents[1]))
-from deplex_amd import build as _b
-os.environ["DPX_LIB_PATH"] = str(_b.build_variant("trace"))  # the product build carries no trace code
+_root = _P(__file__).resolve().parents[1]
+# the product build carries no trace code: build (in a child process: importing the package here would fix the library
+# path) and select the -DDPX_TRACE variant
+subprocess.run([sys.executable, "-c", "from deplex_amd import build as b; b.build_variant('trace')"], cwd=str(_root), check=True)
+os.environ["DPX_LIB_PATH"] = str(_root / "deplex_amd" / "lib" / "variants" / "trace.so")
 if len(sys.argv) > 2: os.environ["DPX_SKIP"] = sys.argv[2]
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
