@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 # plane-fit kernel (depth): VALU instructions per pixel / per cell in the ISA and the chip's
 # measured VALU rates in T lane-operations/s (tools/ubench/pk.hip on MI355X: dependent v_mul->v_add pairs at >= 2 waves
 # per SIMD; v_fma_f32)
-VALU_PER_PIXEL, VALU_PER_CELL = 23.3, 1070
+VALU_PER_PIXEL, VALU_PER_CELL = 22.0, 1000
 VALU_PEAK_MULADD_TOPS, VALU_PEAK_FMA_TOPS = 62.7, 39.6
 
 
