@@ -205,10 +205,8 @@ def main():
     if args.roofline_only:
         cloud = args.roofline_input == "cloud"
         ms, by = planefit_series(cloud, args.roofline_iters)
-        if cloud:  # launched per submission: G launches of B frames in the series
-            ms, by = ms / G, by // G
         print(json.dumps({"roofline_only": True, "kernel": "k_planefit_cloud_lds" if cloud else "k_planefit_depth", "batch": B,
-                          "frames_per_launch": B if cloud else G * B, "workload": args.workload, "avg_launch_ms": round(ms, 4), "bytes_per_launch": by,
+                          "frames_per_launch": G * B, "workload": args.workload, "avg_launch_ms": round(ms, 4), "bytes_per_launch": by,
                           "achieved_GBps": round(by / (ms * 1e-3) / 1e9, 1), "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}))
         return
     elapsed = timed_region(step, sync, barrier, args.steps, args.warmup)
@@ -271,7 +269,8 @@ def main():
                 tj = json.loads(tfile.read_text())
                 if tj.get("frames_per_launch") == G * B and tj.get("workload") == args.workload:
                     traffic = tj.get("hbm_bytes_per_launch")
-                    cloud_traffic = tj.get("cloud", {}).get("hbm_bytes_per_launch")
+                    if tj.get("cloud", {}).get("frames_per_launch") == G * B:
+                        cloud_traffic = tj["cloud"].get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         # lane-operations of the exact arithmetic in the kernel's ISA: VALU_PER_PIXEL per pixel
@@ -305,12 +304,11 @@ def main():
                                          "note": f"HIP events around the launches of the timed steps with {S} groups of {G} batches in flight (includes queueing behind / sharing with the other groups' kernels)"}},
         }
         if cloud_ms:
-            # (the cloud kernel is launched per submission: the group's series is G launches of B frames, G distinct buffers)
             out["roofline_cloud_input"] = {"kernel": "k_planefit_cloud_lds (organised xyz cloud -> per-cell moments + eigen plane fit), "
-                                                     f"one launch per submission of {B} frames",
+                                                     f"one launch per group of {G} submissions = {G * B} frames",
                                            "bound": "hbm", "achieved": round(cloud_bytes / (cloud_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": round(cloud_bytes / (cloud_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                           "traffic": cloud_traffic, "bytes_per_launch": cloud_bytes // G, "avg_launch_ms": round(cloud_ms / G, 4)}
+                                           "traffic": cloud_traffic, "bytes_per_launch": cloud_bytes, "avg_launch_ms": round(cloud_ms, 4)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(depth, intr, min(16, os.cpu_count() or 1))  # the box's CPU share for one GPU
         print(json.dumps(out), flush=True)

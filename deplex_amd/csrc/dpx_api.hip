@@ -222,20 +222,34 @@ void launch_planefit(const dpx::Params& prm, const void* d_in, dpx_cell* d_cells
   }
 }
 
+// LDS-staged cloud kernel: needs 16-byte aligned row segments (W % 4 == 0 and aligned clouds); takes a whole group
+bool cloud_lds_path(dpx_handle h, const dpx::Params& prm) {
+  const char* v1 = std::getenv("DPX_PLANEFIT_V1");
+  return fast_shape(prm) && !(v1 && v1[0] == '1') && !h->opt_cloud_nolds && (prm.W & 3) == 0;
+}
+
+void launch_planefit_cloud_group(const dpx::Params& prm, const dpx::PfGroup& grp, dpx_cell* d_cells, hipStream_t s) {
+  const long long waves = static_cast<long long>(prm.batch) * prm.nv * ((prm.nh + 63) / 64);
+  const unsigned blocks = static_cast<unsigned>((waves + 3) / 4);
+  switch (prm.P) {
+    case 4: hipLaunchKernelGGL((dpx::k_planefit_cloud_lds<4>), dim3(blocks), dim3(256), 0, s, prm, grp, d_cells); return;
+    case 8: hipLaunchKernelGGL((dpx::k_planefit_cloud_lds<8>), dim3(blocks), dim3(256), 0, s, prm, grp, d_cells); return;
+    default: hipLaunchKernelGGL((dpx::k_planefit_cloud_lds<10>), dim3(blocks), dim3(256), 0, s, prm, grp, d_cells); return;
+  }
+}
+
 void launch_planefit_cloud(dpx_handle h, const dpx::Params& prm, const void* d_in, dpx_cell* d_cells, hipStream_t s) {
   const char* v1 = std::getenv("DPX_PLANEFIT_V1");
   if (fast_shape(prm) && !(v1 && v1[0] == '1')) {
     const long long waves = static_cast<long long>(prm.batch) * prm.nv * ((prm.nh + 63) / 64);
     const unsigned blocks = static_cast<unsigned>((waves + 3) / 4);
     const float* xyz = static_cast<const float*>(d_in);
-    // LDS-staged form: needs 16-byte aligned row segments (W % 4 == 0 and an aligned cloud)
-    if (!h->opt_cloud_nolds && (prm.W & 3) == 0 && (reinterpret_cast<uintptr_t>(d_in) & 15u) == 0) {
-      switch (prm.P) {
-        case 4: hipLaunchKernelGGL((dpx::k_planefit_cloud_lds<4>), dim3(blocks), dim3(256), 0, s, prm, xyz, d_cells); return;
-        case 8: hipLaunchKernelGGL((dpx::k_planefit_cloud_lds<8>), dim3(blocks), dim3(256), 0, s, prm, xyz, d_cells); return;
-        case 10: hipLaunchKernelGGL((dpx::k_planefit_cloud_lds<10>), dim3(blocks), dim3(256), 0, s, prm, xyz, d_cells); return;
-        default: break;
-      }
+    if (cloud_lds_path(h, prm) && (reinterpret_cast<uintptr_t>(d_in) & 15u) == 0) {
+      dpx::PfGroup grp{};
+      for (int q = 0; q < 8; ++q) grp.in[q] = d_in;
+      grp.per_sub = prm.batch;
+      launch_planefit_cloud_group(prm, grp, d_cells, s);
+      return;
     }
     switch (prm.P) {
       case 4: hipLaunchKernelGGL((dpx::k_planefit_cloud<4>), dim3(blocks), dim3(256), 0, s, prm, xyz, d_cells); return;
@@ -326,7 +340,16 @@ int stage_fit(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool de
   if (h->prm.C > 0 && !skip_f) {
     bool one_launch = depth && depth_fast_path(h->prm);
     for (int j = 1; j < nsub && one_launch; ++j) one_launch = subs[j].fd_ok == subs[0].fd_ok;
-    if (one_launch) {
+    bool cloud_group = !depth && cloud_lds_path(h, h->prm);
+    for (int j = 0; j < nsub && cloud_group; ++j) cloud_group = (reinterpret_cast<uintptr_t>(subs[j].d_in) & 15u) == 0;
+    if (cloud_group) {
+      dpx::Params prm = h->prm;
+      prm.batch = batch;
+      dpx::PfGroup grp{};
+      for (int j = 0; j < 8; ++j) grp.in[j] = subs[j < nsub ? j : 0].d_in;
+      grp.per_sub = per_sub;
+      launch_planefit_cloud_group(prm, grp, h->d_cells, s);
+    } else if (one_launch) {
       dpx::Params prm = h->prm;
       prm.batch = batch;
       dpx::PfGroup grp{};

@@ -635,7 +635,7 @@ struct CloudStage {
   }
 
 template <int P>
-__global__ __launch_bounds__(256, DPX_CLOUD_WAVES) void k_planefit_cloud_lds(Params prm, const float* __restrict__ xyz, dpx_cell* __restrict__ cells) {
+__global__ __launch_bounds__(256, DPX_CLOUD_WAVES) void k_planefit_cloud_lds(Params prm, PfGroup grp, dpx_cell* __restrict__ cells) {
   static_assert(P % 2 == 0 && P >= 2, "even patch sizes only");
   constexpr int n = P * P;
   constexpr int A2 = (n / 8) * 8;
@@ -657,7 +657,10 @@ __global__ __launch_bounds__(256, DPX_CLOUD_WAVES) void k_planefit_cloud_lds(Par
   const int ncell = (prm.nh - cc0) < 64 ? (prm.nh - cc0) : 64;
   const int last_dw = ncell * 3 * P - 4;  // first dword of the segment's last whole chunk
   const long long row_stride = 3ll * prm.W;
-  const float* seg0 = xyz + 3ll * (static_cast<long long>(frame) * prm.N + static_cast<long long>(cr) * P * prm.W + static_cast<long long>(cc0) * P);
+  // one launch covers the submissions of a pipeline group (PfGroup): this wave's cloud
+  const int sub = __builtin_amdgcn_readfirstlane(frame / grp.per_sub);
+  const float* xyz = static_cast<const float*>(grp.in[sub]);
+  const float* seg0 = xyz + 3ll * (static_cast<long long>(frame - sub * grp.per_sub) * prm.N + static_cast<long long>(cr) * P * prm.W + static_cast<long long>(cc0) * P);
   float* lds = stage_lds + wid * 2 * kWaveFloats;
 
   CellAcc<P, false> acc;
