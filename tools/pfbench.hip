@@ -1,6 +1,6 @@
 // pfbench — stand-alone timing / diagnosis harness for the depth plane-fit kernels (not part of the product).
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -o tools/pfbench tools/pfbench.hip
-//   tools/pfbench <depth.bin (u16 [B][480][640])> <B> [iters]
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 [-DPFBENCH_STAMPS] -o tools/pfbench tools/pfbench.hip
+//   python tools/dump_stream.py /tmp/tum64.bin 64 && tools/pfbench /tmp/tum64.bin 64 [iters] [1 = print stamps]
 // Runs every kernel variant on the same frames, compares the cell records bit for bit with variant 0 (the
 // product kernel) and prints per-launch time; with stamps it also prints where the waves ran and for how long.
 #include <hip/hip_runtime.h>
@@ -11,7 +11,10 @@
 #include <map>
 #include <vector>
 
+// -DPFBENCH_STAMPS compiles the per-wave s_memtime stamps in (they cost the kernel registers: its timings are then no
+// longer those of the product kernel; use the stamps for the shape of a launch, the plain build for its duration).
 __device__ unsigned long long* g_stamps = nullptr;
+#ifdef PFBENCH_STAMPS
 #define DPX_PF_STAMP(slot)                                                                          \
   if (g_stamps && lane == 0) {                                                                      \
     g_stamps[wave * 4 + (slot)] = __builtin_readcyclecounter();                                     \
@@ -19,6 +22,7 @@ __device__ unsigned long long* g_stamps = nullptr;
       g_stamps[wave * 4 + 3] = (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((31 << 11) | 20)) << 32) | \
                                __builtin_amdgcn_s_getreg((31 << 11) | 4);                           \
   }
+#endif
 
 #include "../deplex_amd/csrc/dpx_planefit_fast.h"
 #if __has_include("../deplex_amd/csrc/dpx_planefit_v2.h")

@@ -1,4 +1,4 @@
-"""Diagnostic: per-phase shader-clock cycles of the region-growing kernel (s_memtime, 100 MHz on gfx950).
+"""Diagnostic: per-phase shader-clock cycles of the region-growing kernel (s_memtime: the shader clock, 2.4 GHz under load on MI355X; s_memrealtime is the 100 MHz one).
 usage: region_phases.py [H W batch]   (default: the bench workload, 64 TUM-like 640x480 frames)"""
 import sys
 from pathlib import Path
