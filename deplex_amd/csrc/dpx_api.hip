@@ -963,7 +963,12 @@ int dpx_read_depth_png(const char* path, int32_t* height, int32_t* width, uint16
   if (!path || !height || !width || !data) return fail(DPX_ERR_ARG, "null argument");
   *data = nullptr;
   dpxpng::Image img;
-  const std::string err = dpxpng::read_grey16(path, img);
+  std::string err;
+  try {
+    err = dpxpng::read_grey16(path, img);
+  } catch (const std::exception& e) {  // (allocation failure on a hostile file: no exception crosses the C boundary)
+    err = e.what();
+  }
   if (!err.empty()) return fail(DPX_ERR_IO, std::string("Error: Couldn't read image ") + path);  // depth_image.cpp:33
   const size_t n = static_cast<size_t>(img.width) * img.height;
   uint16_t* buf = static_cast<uint16_t*>(std::malloc(std::max<size_t>(n, 1) * sizeof(uint16_t)));

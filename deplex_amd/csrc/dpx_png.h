@@ -91,6 +91,7 @@ inline std::string read_grey16(const char* path, Image& out) {
   }
   (void)has_trns;
   if (ctype < 0 || W == 0 || H == 0 || W > (1u << 24) || H > (1u << 24)) return "missing or invalid IHDR";
+  if (static_cast<unsigned long long>(W) * H > (1ull << 28)) return "image too large";  // (a header can claim anything)
   int channels;
   switch (ctype) {
     case 0: channels = 1; break;
