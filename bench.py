@@ -97,10 +97,12 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("DPX_BENCH_STREAMS", 16)))
-    # submissions per launch sequence: 8 is 2 % faster in steady state (1.48 vs 1.45 M frames/s at 2000 steps); 5 divides
-    # short runs (the driver's 20 steps) into whole groups, worth 10 % there (1.19 vs 1.08 M) — measured, DESIGN.md section 5
-    ap.add_argument("--group", type=int, default=int(os.environ.get("DPX_BENCH_GROUP", 5)), help="submissions per launch sequence (1..8)")
+    # Pipeline shape.  0 = chosen from the run length: long runs (>= 100 steps) 4 slots x groups of 8 — one hardware queue
+    # per compute pipe, measured 1.65-1.70 M frames/s against 1.55-1.60 M with 16 slots and 1.52-1.55 M with 5 or 6 —
+    # short runs (the driver's 20 steps) 16 slots x groups of 5, which divides them into whole groups (1.24-1.28 M
+    # against 1.20-1.24 M with 4 slots and 1.08 M with groups of 8).  DESIGN.md section 5.
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("DPX_BENCH_STREAMS", 0)), help="groups in flight (pipeline slots); 0 = auto")
+    ap.add_argument("--group", type=int, default=int(os.environ.get("DPX_BENCH_GROUP", 0)), help="submissions per launch sequence (1..8); 0 = auto")
     ap.add_argument("--prof-every", type=int, default=16, help="record per-kernel HIP events on every n-th slot")
     ap.add_argument("--roofline-iters", type=int, default=50)
     ap.add_argument("--no-cloud-roofline", action="store_true")
@@ -136,8 +138,9 @@ def main():
             dist.init_process_group(backend)
     import deplex_amd as D
 
-    S = max(1, args.streams)  # groups in flight (pipeline slots), one stream each
-    G = max(1, min(8, args.group))
+    long_run = args.steps >= 100
+    S = args.streams if args.streams > 0 else (4 if long_run else 16)  # groups in flight (pipeline slots), one stream each
+    G = max(1, min(8, args.group)) if args.group > 0 else (8 if long_run else 5)
     # The steps rotate over R distinct input batches (R divides the S*G output buffers, so buffer k always holds the
     # result of input k % R): together larger than the 256 MB Infinity Cache, i.e. the frames stream from HBM.
     R = max(1, min(args.inputs, S * G))
@@ -152,7 +155,7 @@ def main():
     d_depths = [torch.from_numpy(d.view(np.int16)).to(dev) for d in depths]
     d_depth = d_depths[0]
     d_labels = torch.empty((S * G, B, N), dtype=torch.int32, device=dev)
-    pipe = D.Pipeline(H, W, D.Config(), batch=B, slots=S, group=args.group, device=local_rank)
+    pipe = D.Pipeline(H, W, D.Config(), batch=B, slots=S, group=G, device=local_rank)
     exs = [pipe.slot(k) for k in range(S)]
     for ex in exs:
         ex.prepare_intrinsics(*intr)  # one-time exact-division check, outside the timed region
@@ -267,10 +270,13 @@ def main():
         if tfile.exists():
             try:
                 tj = json.loads(tfile.read_text())
-                if tj.get("frames_per_launch") == G * B and tj.get("workload") == args.workload:
-                    traffic = tj.get("hbm_bytes_per_launch")
-                    if tj.get("cloud", {}).get("frames_per_launch") == G * B:
-                        cloud_traffic = tj["cloud"].get("hbm_bytes_per_launch")
+                # measured per launch of `frames_per_launch` frames; a launch's traffic is proportional to its frames
+                # (every wave reads its own rows once), so other group sizes are scaled
+                if tj.get("workload") == args.workload and tj.get("frames_per_launch"):
+                    traffic = int(round(tj["hbm_bytes_per_launch"] / tj["frames_per_launch"] * G * B))
+                    c = tj.get("cloud", {})
+                    if c.get("frames_per_launch"):
+                        cloud_traffic = int(round(c["hbm_bytes_per_launch"] / c["frames_per_launch"] * G * B))
             except Exception:
                 traffic = None
         # lane-operations of the exact arithmetic in the kernel's ISA: VALU_PER_PIXEL per pixel
