@@ -102,7 +102,7 @@ def main():
     # short runs (the driver's 20 steps) 16 slots x groups of 5, which divides them into whole groups (1.24-1.28 M
     # against 1.20-1.24 M with 4 slots and 1.08 M with groups of 8).  DESIGN.md section 5.
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DPX_BENCH_STREAMS", 0)), help="groups in flight (pipeline slots); 0 = auto")
-    ap.add_argument("--group", type=int, default=int(os.environ.get("DPX_BENCH_GROUP", 0)), help="submissions per launch sequence (1..8); 0 = auto")
+    ap.add_argument("--group", type=int, default=int(os.environ.get("DPX_BENCH_GROUP", 0)), help="submissions per launch sequence (1..32); 0 = auto")
     ap.add_argument("--prof-every", type=int, default=16, help="record per-kernel HIP events on every n-th slot")
     ap.add_argument("--roofline-iters", type=int, default=50)
     ap.add_argument("--no-cloud-roofline", action="store_true")
@@ -140,7 +140,7 @@ def main():
 
     long_run = args.steps >= 100
     S = args.streams if args.streams > 0 else (4 if long_run else 16)  # groups in flight (pipeline slots), one stream each
-    G = max(1, min(8, args.group)) if args.group > 0 else (8 if long_run else 5)
+    G = max(1, min(32, args.group)) if args.group > 0 else (8 if long_run else 5)
     # The steps rotate over R distinct input batches (R divides the S*G output buffers, so buffer k always holds the
     # result of input k % R): together larger than the 256 MB Infinity Cache, i.e. the frames stream from HBM.
     R = max(1, min(args.inputs, S * G))

@@ -246,7 +246,7 @@ void launch_planefit_cloud(dpx_handle h, const dpx::Params& prm, const void* d_i
     const float* xyz = static_cast<const float*>(d_in);
     if (cloud_lds_path(h, prm) && (reinterpret_cast<uintptr_t>(d_in) & 15u) == 0) {
       dpx::PfGroup grp{};
-      for (int q = 0; q < 8; ++q) grp.in[q] = d_in;
+      for (int q = 0; q < dpx::kMaxGroup; ++q) grp.in[q] = d_in;
       grp.per_sub = prm.batch;
       launch_planefit_cloud_group(prm, grp, d_cells, s);
       return;
@@ -324,7 +324,7 @@ int fill_sub(dpx_handle h, SubBatch& sb, const void* d_in, int32_t* d_labels, bo
 
 int stage_fit(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool depth, hipStream_t s, bool allow_skip = true) {
   const int batch = nsub * per_sub;
-  if (nsub < 1 || nsub > 8 || per_sub < 0 || batch > h->max_batch)
+  if (nsub < 1 || nsub > dpx::kMaxGroup || per_sub < 0 || batch > h->max_batch)
     return fail(DPX_ERR_ARG, "batch " + std::to_string(batch) + " exceeds max_batch " + std::to_string(h->max_batch));
   DPX_HIP(hipSetDevice(h->device));
   if (batch == 0) return DPX_OK;
@@ -346,14 +346,14 @@ int stage_fit(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool de
       dpx::Params prm = h->prm;
       prm.batch = batch;
       dpx::PfGroup grp{};
-      for (int j = 0; j < 8; ++j) grp.in[j] = subs[j < nsub ? j : 0].d_in;
+      for (int j = 0; j < dpx::kMaxGroup; ++j) grp.in[j] = subs[j < nsub ? j : 0].d_in;
       grp.per_sub = per_sub;
       launch_planefit_cloud_group(prm, grp, h->d_cells, s);
     } else if (one_launch) {
       dpx::Params prm = h->prm;
       prm.batch = batch;
       dpx::PfGroup grp{};
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < dpx::kMaxGroup; ++j) {
         const SubBatch& b = subs[j < nsub ? j : 0];
         grp.in[j] = b.d_in;
         grp.fx[j] = b.fx; grp.fy[j] = b.fy; grp.cx[j] = b.cx; grp.cy[j] = b.cy; grp.rx[j] = b.rx; grp.ry[j] = b.ry;
@@ -368,7 +368,7 @@ int stage_fit(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool de
         dpx_cell* out = h->d_cells + static_cast<size_t>(j) * per_sub * prm.C;
         if (depth && depth_fast_path(prm)) {
           dpx::PfGroup grp{};
-          for (int q = 0; q < 8; ++q) {
+          for (int q = 0; q < dpx::kMaxGroup; ++q) {
             grp.in[q] = subs[j].d_in;
             grp.fx[q] = subs[j].fx; grp.fy[q] = subs[j].fy; grp.cx[q] = subs[j].cx; grp.cy[q] = subs[j].cy;
             grp.rx[q] = subs[j].rx; grp.ry[q] = subs[j].ry;
@@ -389,7 +389,7 @@ int stage_fit(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool de
 
 int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool depth, hipStream_t s) {
   const int batch = nsub * per_sub;
-  if (nsub < 1 || nsub > 8 || batch > h->max_batch) return fail(DPX_ERR_ARG, "bad sub-batch grouping");
+  if (nsub < 1 || nsub > dpx::kMaxGroup || batch > h->max_batch) return fail(DPX_ERR_ARG, "bad sub-batch grouping");
   DPX_HIP(hipSetDevice(h->device));
   h->last_stream = s;
   h->last_batch = batch;
@@ -423,7 +423,7 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   rx.bin_off = h->d_bin_off;
   rx.g_qpos = h->d_gqpos;
   rx.frames_per_out = per_sub;
-  for (int j = 0; j < 8; ++j) rx.labels_out[j] = (fuse_labels && j < nsub) ? subs[j].d_labels : nullptr;
+  for (int j = 0; j < dpx::kMaxGroup; ++j) rx.labels_out[j] = (fuse_labels && j < nsub) ? subs[j].d_labels : nullptr;
   if (skip_r) {
   } else if (h->regions_tier == 1 && h->regions_split && !h->d_dbg) {
     hipLaunchKernelGGL((dpx::k_regions2<1, false, 1>), dim3(batch), dim3(dpx::kRT), h->lds2_p1, s, prm, rb, rx);
@@ -461,7 +461,7 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
     if ((prm.W & 3) == 0 && prm.nv + 1 <= 65535 && !labels_v1) {
       // one launch for the whole group: block (frame, cell row) finds its output buffer through `outs`
       dpx::LabelOuts outs{};
-      for (int j = 0; j < 8; ++j) outs.out[j] = j < nsub ? subs[j].d_labels : nullptr;
+      for (int j = 0; j < dpx::kMaxGroup; ++j) outs.out[j] = j < nsub ? subs[j].d_labels : nullptr;
       outs.per_out = per_sub;
       const int extra = prm.H > prm.nv * prm.P ? 1 : 0;
       if (prm.nv + extra > 0) {
@@ -1138,7 +1138,7 @@ int dpx_pipeline_create(const dpx_config* cfg, int32_t image_height, int32_t ima
   if (!out || slots < 1 || batch < 1) return fail(DPX_ERR_ARG, "bad pipeline arguments");
   *out = nullptr;
   if (group < 1) group = 1;
-  if (group > 8) group = 8;
+  if (group > dpx::kMaxGroup) group = dpx::kMaxGroup;
   dpx_pipeline p = new dpx_pipeline_s();
   p->device = device;
   p->group = group;
@@ -1264,11 +1264,11 @@ int dpx_get_kernel_ms(dpx_handle h, float* ms) {
 
 int dpx_time_planefit_group(dpx_handle h, const void* const* d_in, int32_t nsub, int32_t input_kind, int32_t per_sub, float fx,
                             float fy, float cx, float cy, int32_t iters, void* hip_stream, float* avg_ms) {
-  if (!h || !d_in || !avg_ms || iters < 1 || nsub < 1 || nsub > 8) return fail(DPX_ERR_ARG, "bad argument");
+  if (!h || !d_in || !avg_ms || iters < 1 || nsub < 1 || nsub > dpx::kMaxGroup) return fail(DPX_ERR_ARG, "bad argument");
   if (per_sub < 1 || nsub * per_sub > h->max_batch) return fail(DPX_ERR_ARG, "batch out of range");
   DPX_HIP(hipSetDevice(h->device));
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
-  SubBatch subs[8];
+  SubBatch subs[dpx::kMaxGroup];
   for (int j = 0; j < nsub; ++j) {
     if (!d_in[j]) return fail(DPX_ERR_ARG, "null input buffer");
     // (the one-time verification of the reciprocal division synchronises: it happens here, before the timing)

@@ -19,6 +19,10 @@
 
 namespace dpx {
 
+// Most submissions a dpx_pipeline group may hold (sizes the per-submission tables passed to the group launches as kernel
+// arguments; include/deplex_amd.h documents the same limit).
+constexpr int kMaxGroup = 32;
+
 // operand types of the gfx950 LDS-DMA loads (__builtin_amdgcn_global_load_lds)
 typedef __attribute__((address_space(3))) void* dpx_lds_ptr;
 typedef const __attribute__((address_space(1))) void* dpx_glb_ptr;
@@ -550,9 +554,9 @@ __global__ __launch_bounds__(256) void k_labels(Params prm, const int32_t* __res
 // bytes and almost no arithmetic.  The cell labels of the row (nh * 4 bytes) are read straight from global memory
 // (L1/L2 hits): the kernel allocates NO LDS, so its blocks also fit on CUs whose LDS is filled by region workgroups.
 // blockIdx.y == nv handles the image rows below the last full cell row (H % P != 0), which are 0.
-// Frames of a grouped submission go to up to eight output buffers (`per_out` frames each).
+// Frames of a grouped submission go to up to kMaxGroup output buffers (`per_out` frames each).
 struct LabelOuts {
-  int32_t* out[8];
+  int32_t* out[kMaxGroup];
   int per_out;
 };
 // Block b takes the (frame, cell row) tasks b, b + gridDim.x, ...: the host starts one block per CU (a few dozen blocks

@@ -299,12 +299,12 @@ __device__ __forceinline__ void load_cell_row(const uint16_t* rowp, uint32_t (&w
 #endif
 }
 
-// One launch fits the frames of up to 8 submissions (a dpx_pipeline group): frame f of the launch belongs to
+// One launch fits the frames of up to kMaxGroup submissions (a dpx_pipeline group): frame f of the launch belongs to
 // submission f / per_sub, which has its own input buffer and its own intrinsics (and verified reciprocals).  The cell
 // records of all submissions are contiguous (frame-major), as the region kernels expect.
 struct PfGroup {
-  const void* in[8];
-  float fx[8], fy[8], cx[8], cy[8], rx[8], ry[8];
+  const void* in[kMaxGroup];
+  float fx[kMaxGroup], fy[kMaxGroup], cx[kMaxGroup], cy[kMaxGroup], rx[kMaxGroup], ry[kMaxGroup];
   int per_sub;
 };
 

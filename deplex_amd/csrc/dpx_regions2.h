@@ -122,7 +122,7 @@ struct Regions2Extra {
   int sort_pad;             // tier 2: power of two >= C, slots of the in-LDS seed-list sort
   int csr_chunk;            // merge phase: rows with more adjacency entries than this (<= 64) use the bit-row walk
   unsigned long long* res;  // diagnostic (DPX_RESIDENCY=1): [B][4] shader-clock lifetime of the frame's workgroup in launch 1, 2, 3
-  int32_t* labels_out[8];   // non-null: the tail also expands the cell labels to the pixel label map (fused K6);
+  int32_t* labels_out[kMaxGroup];   // non-null: the tail also expands the cell labels to the pixel label map (fused K6);
   int frames_per_out;       // frame f writes to labels_out[f / frames_per_out] (grouped submissions have one buffer each)
 };
 

@@ -17,6 +17,7 @@ from . import _capi
 from ._capi import DeplexError, DpxConfig
 
 _FIELDS = [f[0] for f in DpxConfig._fields_]
+MAX_GROUP = 32  # submissions per pipeline group (dpx::kMaxGroup)
 
 
 class Config:
@@ -238,7 +239,7 @@ class Pipeline:
         cfg = config if config is not None else Config()
         self.config, self.device = cfg, int(device)
         self.image_height, self.image_width, self.batch, self.slots = int(image_height), int(image_width), int(batch), int(slots)
-        self.group = max(1, min(8, int(group)))
+        self.group = max(1, min(MAX_GROUP, int(group)))
         _capi.check(_capi.lib().dpx_pipeline_create(C.byref(cfg._c), self.image_height, self.image_width, self.batch,
                                                    int(device), self.slots, int(group), C.byref(self._p)))
 

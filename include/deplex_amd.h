@@ -133,7 +133,7 @@ int dpx_process_depth_batch_device(dpx_handle h, const void* d_depth, int32_t ba
 int dpx_process_pcd_batch_device(dpx_handle h, const void* d_xyz, int32_t batch, void* d_labels, void* hip_stream);
 
 /* Streamed processing (the reference's examples/process_sequence.cpp:30-53 loop, pipelined).  `slots` groups of
- * `group` (1..8) submissions are in flight, each slot with its own scratch and stream.  A submission is recorded and
+ * `group` (1..32) submissions are in flight, each slot with its own scratch and stream.  A submission is recorded and
  * the whole group is launched when it is full (or at dpx_pipeline_sync): ONE plane-fit launch over all its frames (each
  * submission keeps its own input buffer and intrinsics), then region growing and label expansion, also one launch
  * sequence per group (the GPU executes only a handful of kernels concurrently and a launch per small batch leaves the
@@ -188,7 +188,7 @@ int dpx_get_kernel_ms(dpx_handle h, float* ms /* DPX_K_COUNT */);
  * average duration in ms measured with HIP events on that stream (input_kind: 0 depth uint16, 1 xyz float32). */
 int dpx_time_planefit(dpx_handle h, const void* d_in, int32_t input_kind, int32_t batch, float fx, float fy,
                       float cx, float cy, int32_t iters, void* hip_stream, float* avg_ms);
-/* The same for a pipeline group: ONE launch over `nsub` (1..8) device buffers of `per_sub` frames each, the launch
+/* The same for a pipeline group: ONE launch over `nsub` (1..32) device buffers of `per_sub` frames each, the launch
  * shape dpx_pipeline uses (nsub * per_sub <= max_batch of the handle). */
 int dpx_time_planefit_group(dpx_handle h, const void* const* d_in, int32_t nsub, int32_t input_kind, int32_t per_sub,
                             float fx, float fy, float cx, float cy, int32_t iters, void* hip_stream, float* avg_ms);

@@ -523,6 +523,38 @@ def test_pipeline_group_with_mixed_intrinsics(D, oracle):
             del view
 
 
+def test_pipeline_group_of_many_submissions(D, oracle):
+    """A group holds up to 32 submissions (the per-submission tables of the group launches are kernel arguments): 11
+    single-frame submissions with alternating intrinsics in groups of 11 and of 32 (flushed partly filled by sync),
+    depth and cloud input, every label map against the oracle; a larger request is clamped to 32."""
+    import torch
+    h, w, n = 240, 320, 11
+    ia = synth.intrinsics_for(h, w)
+    ib = tuple(float(np.float32(v)) for v in (ia[0] * 0.96, ia[1] * 1.03, ia[2] - 1.75, ia[3] + 4.5))
+    dev = torch.device("cuda", 0)
+    frames = [synth.synth_batch(1, h, w, seed0=900 + 3 * i) for i in range(n)]
+    intrs = [ia if i % 3 else ib for i in range(n)]
+    oracle.set_math("devmath")
+    ocfg = oracle.default_config()
+    cfg = to_cfg(D, ocfg)
+    refs = [oracle.process_depth_batch(ocfg, f, *k, threads=2) for f, k in zip(frames, intrs)]
+    d_depth = [torch.from_numpy(f.view(np.int16)).to(dev) for f in frames]
+    d_cloud = [torch.from_numpy(np.ascontiguousarray(oracle.backproject(f[0], *k))).to(dev) for f, k in zip(frames, intrs)]
+    assert D.Pipeline(h, w, cfg, batch=1, slots=1, group=1000).group == 32
+    for group in (11, 32):
+        for cloud in (False, True):
+            d_out = [torch.full((1, h * w), -1, dtype=torch.int32, device=dev) for _ in range(n)]
+            pipe = D.Pipeline(h, w, cfg, batch=1, slots=2, group=group)
+            for i in range(n):
+                if cloud:
+                    pipe.submit_pcd(d_cloud[i].data_ptr(), 1, d_out[i].data_ptr())
+                else:
+                    pipe.submit_depth(d_depth[i].data_ptr(), 1, *intrs[i], d_out[i].data_ptr())
+            pipe.sync()
+            for i in range(n):
+                assert np.array_equal(d_out[i].cpu().numpy(), refs[i]), f"group {group} cloud {cloud} submission {i}"
+
+
 def test_host_batches_with_records(D, oracle):
     """Larger host-pointer batches (depth, cloud, lean tier, refinement): labels, per-frame records and statistics of
     every frame."""

@@ -49,7 +49,7 @@ template <int MODE>
 static void launch_v0(const dpx::Params& prm, const uint16_t* d, dpx_cell* c, float rx, float ry, hipStream_t s) {
   const long long waves = static_cast<long long>(prm.batch) * prm.nv * ((prm.nh + 63) / 64);
   const unsigned blocks = static_cast<unsigned>((waves + 3) / 4);
-  dpx::PfGroup g{}; for (int j = 0; j < 8; ++j) { g.in[j] = d; g.fx[j] = prm.fx; g.fy[j] = prm.fy; g.cx[j] = prm.cx; g.cy[j] = prm.cy; g.rx[j] = rx; g.ry[j] = ry; } g.per_sub = prm.batch;
+  dpx::PfGroup g{}; for (int j = 0; j < dpx::kMaxGroup; ++j) { g.in[j] = d; g.fx[j] = prm.fx; g.fy[j] = prm.fy; g.cx[j] = prm.cx; g.cy[j] = prm.cy; g.rx[j] = rx; g.ry[j] = ry; } g.per_sub = prm.batch;
   hipLaunchKernelGGL((dpx::k_planefit_depth<10, true, MODE>), dim3(blocks), dim3(256), 0, s, prm, g, c);
 }
 
