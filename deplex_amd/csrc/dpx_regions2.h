@@ -1189,56 +1189,97 @@ __global__ __launch_bounds__(kRT) void k_region_prep(Params prm, RegionBufs rb, 
   __syncthreads();
   {
     int planar_cnt = 0;
-    for (int c0 = 0; c0 < C; c0 += kRT) {  // (uniform trip count: the key compaction below uses wave ballots)
-      const int c = c0 + tid < C ? c0 + tid : C - 1;
-      const bool live = c0 + tid < C;
-      // fused K3 (k_cellgraph): planar bit, histogram bin and the four IN-edges of the growSeed predicate
-      // (plane_extractor.cpp:377-383) straight from the plane-fit records
-      const float4* rc = reinterpret_cast<const float4*>(cells + c);
-      const float4 q2 = rc[2], q3 = rc[3];  // {pp5, n0, n1, n2}, {d, mse, tol, info}
-      const uint32_t info = __float_as_uint(q3.w);
-      uint32_t fl = (info & CELL_PLANAR) ? F_UNASSIGNED : 0u;
-      const uint32_t bin1 = (info & CELL_PLANAR) ? (info >> 8) : 0u;
-      if (fl) {
-        const float4 q0 = rc[0];
-        const float nf = static_cast<float>(prm.n);
-        const float smx = q0.x / nf, smy = q0.y / nf, smz = q0.z / nf;  // mean_ = coord_sum_ / nr_pts_
-        const double tol_self = static_cast<double>(q3.z);
-        const int cr = c / nh, cc = c - cr * nh;
-        const int nbr[4] = {cr >= 1 ? c - nh : -1, cr + 1 < nv ? c + nh : -1, cc >= 1 ? c - 1 : -1, cc + 1 < nh ? c + 1 : -1};
+    // Fused K3 (k_cellgraph): planar bit, histogram bin and the four IN-edges of the growSeed predicate
+    // (plane_extractor.cpp:377-383) straight from the plane-fit records.  A wave walks down a strip of 64 grid columns,
+    // one grid row per step: the records of the row above and below are the previous and the next step's own loads
+    // (kept in registers, the next row in flight while this one is evaluated), the left and right neighbours come from
+    // the adjacent lanes.  The records are 64-byte structs, so every float4 load of a wave touches 64 cache lines
+    // however it is arranged; reading each record once instead of five times (itself + as four cells' neighbour) is
+    // what shortens this phase — it was bound by the CU's address coalescer (62 k of the launch's 124 k cycles).
+    struct Row {
+      float4 q0, q2, q3;  // {sum x, y, z, .}, {pp5, n0, n1, n2}, {d, mse, tol, info}
+    };
+    const int strips = (nh + 63) >> 6;
+    const int rows_per_task = (nv + kRW - 1) / kRW;
+    const float nf = static_cast<float>(prm.n);
+    for (int task = wid; task < strips * kRW; task += kRW) {
+      const int strip = task / kRW, r0 = (task - strip * kRW) * rows_per_task;
+      const int r1 = r0 + rows_per_task < nv ? r0 + rows_per_task : nv;
+      const int cc = strip * 64 + lane;
+      const bool col_ok = cc < nh;
+      const int ccl = col_ok ? cc : nh - 1;  // (idle lanes of the last strip read the last column)
+      auto fetch = [&](int r, Row& row) {
+        const float4* rc = reinterpret_cast<const float4*>(cells + (r * nh + ccl));
+        row.q0 = rc[0];
+        row.q2 = rc[2];
+        row.q3 = rc[3];
+      };
+      Row up, cur, down;
+      if (r0 < r1) {
+        fetch(r0 > 0 ? r0 - 1 : r0, up);
+        fetch(r0, cur);
+      }
+      for (int r = r0; r < r1; ++r) {
+        const int c = r * nh + ccl;
+        fetch(r + 1 < nv ? r + 1 : r, down);
+        const float4 q0 = cur.q0, q2 = cur.q2, q3 = cur.q3;
+        const uint32_t info = __float_as_uint(q3.w);
+        // left / right neighbours: the adjacent lanes' records; the strip's edge lanes read them from memory
+        float4 l2, l3, r2, r3;
+        l2.y = __shfl_up(q2.y, 1); l2.z = __shfl_up(q2.z, 1); l2.w = __shfl_up(q2.w, 1); l3.x = __shfl_up(q3.x, 1); l3.w = __shfl_up(q3.w, 1);
+        r2.y = __shfl_down(q2.y, 1); r2.z = __shfl_down(q2.z, 1); r2.w = __shfl_down(q2.w, 1); r3.x = __shfl_down(q3.x, 1); r3.w = __shfl_down(q3.w, 1);
+        if (lane == 0 && cc >= 1) {
+          const float4* rv = reinterpret_cast<const float4*>(cells + (c - 1));
+          const float4 a = rv[2], b = rv[3];
+          l2.y = a.y; l2.z = a.z; l2.w = a.w; l3.x = b.x; l3.w = b.w;
+        }
+        if (lane == 63 && cc + 1 < nh) {
+          const float4* rv = reinterpret_cast<const float4*>(cells + (c + 1));
+          const float4 a = rv[2], b = rv[3];
+          r2.y = a.y; r2.z = a.z; r2.w = a.w; r3.x = b.x; r3.w = b.w;
+        }
+        uint32_t fl = (info & CELL_PLANAR) ? F_UNASSIGNED : 0u;
+        const uint32_t bin1 = (info & CELL_PLANAR) ? (info >> 8) : 0u;
+        if (fl) {
+          const float smx = q0.x / nf, smy = q0.y / nf, smz = q0.z / nf;  // mean_ = coord_sum_ / nr_pts_
+          const double tol_self = static_cast<double>(q3.z);
+          const bool have[4] = {r >= 1, r + 1 < nv, cc >= 1, cc + 1 < nh};
+          const float4 n2[4] = {up.q2, down.q2, l2, r2};
+          const float4 n3[4] = {up.q3, down.q3, l3, r3};
 #pragma unroll
-        for (int dir = 0; dir < 4; ++dir) {
-          const int v = nbr[dir];
-          if (v < 0) continue;
-          const float4* rv = reinterpret_cast<const float4*>(cells + v);
-          const float4 v2 = rv[2], v3 = rv[3];
-          if (!(__float_as_uint(v3.w) & CELL_PLANAR)) continue;
-          const float cosf_ = dot3(q2.y, q2.z, q2.w, v2.y, v2.z, v2.w);  // same products/sum order as n_v . n_c
-          if (!(static_cast<double>(cosf_) >= static_cast<double>(prm.min_cos))) continue;
-          const double ti = static_cast<double>(dot3(v2.y, v2.z, v2.w, smx, smy, smz)) + static_cast<double>(v3.x);
-          if (ti * ti <= tol_self) fl |= (F_EDGE0 << dir);
+          for (int dir = 0; dir < 4; ++dir) {
+            if (!have[dir]) continue;
+            const float4 v2 = n2[dir], v3 = n3[dir];
+            if (!(__float_as_uint(v3.w) & CELL_PLANAR)) continue;
+            const float cosf_ = dot3(q2.y, q2.z, q2.w, v2.y, v2.z, v2.w);  // same products/sum order as n_v . n_c
+            if (!(static_cast<double>(cosf_) >= static_cast<double>(prm.min_cos))) continue;
+            const double ti = static_cast<double>(dot3(v2.y, v2.z, v2.w, smx, smy, smz)) + static_cast<double>(v3.x);
+            if (ti * ti <= tol_self) fl |= (F_EDGE0 << dir);
+          }
         }
-      }
-      // sort key of the seed lists (dpx_binsort.h): bin, then MSE, then cell id
-      const int kb = static_cast<int>(bin1) - 1;
-      const bool has = live && fl && kb >= 0 && kb < nb;
-      if (live) {
-        g_flags[c] = static_cast<uint8_t>(fl);
-        g_binof[c] = static_cast<uint16_t>(bin1);
-        g_qpos[c] = static_cast<uint16_t>(0xFFFFu);
-        if (fl & F_UNASSIGNED) {
-          ++planar_cnt;
-          if (kb >= 0 && kb < nb) atomicAdd(&hist[kb], 1);
+        // sort key of the seed lists (dpx_binsort.h): bin, then MSE, then cell id
+        const int kb = static_cast<int>(bin1) - 1;
+        const bool has = col_ok && fl && kb >= 0 && kb < nb;
+        if (col_ok) {
+          g_flags[c] = static_cast<uint8_t>(fl);
+          g_binof[c] = static_cast<uint16_t>(bin1);
+          g_qpos[c] = static_cast<uint16_t>(0xFFFFu);
+          if (fl & F_UNASSIGNED) {
+            ++planar_cnt;
+            if (kb >= 0 && kb < nb) atomicAdd(&hist[kb], 1);
+          }
         }
+        const unsigned long long hm = __ballot(has);  // compact the keys (any order: they are sorted next)
+        int base = 0;
+        if (lane == 0 && hm) base = atomicAdd(&hdr[6], __popcll(hm));
+        base = __shfl(base, 0);
+        if (has)
+          skeys[base + __popcll(hm & lt_mask)] = (static_cast<unsigned long long>(kb) << kKeyBinShift) |
+                                                 (static_cast<unsigned long long>(sort_mse_key(q3.y)) << kKeyCellBits) |
+                                                 static_cast<unsigned long long>(c);
+        up = cur;
+        cur = down;
       }
-      const unsigned long long hm = __ballot(has);  // compact the keys (any order: they are sorted next)
-      int base = 0;
-      if (lane == 0 && hm) base = atomicAdd(&hdr[6], __popcll(hm));
-      base = __shfl(base, 0);
-      if (has)
-        skeys[base + __popcll(hm & lt_mask)] = (static_cast<unsigned long long>(kb) << kKeyBinShift) |
-                                               (static_cast<unsigned long long>(sort_mse_key(q3.y)) << kKeyCellBits) |
-                                               static_cast<unsigned long long>(c);
     }
     planar_cnt = wave_sum(planar_cnt);
     if (lane == 0) atomicAdd(&hdr[0], planar_cnt);

@@ -23,6 +23,8 @@ def fuzz_pipeline(rng, depth, intr, ocfg, xyz):
         refs.append(O.process(ocfg, H, W, O.backproject(d, *[np.float32(v) for v in intr]), debug=True)[0])
     ref = np.stack(refs)
     slots, group, nsub = int(rng.integers(1, 4)), int(rng.integers(1, 5)), int(rng.integers(1, 8))
+    if rng.random() < 0.25:  # wide groups (up to the 32 submissions a group can hold), more submissions than one group
+        group, nsub = int(rng.integers(5, 33)), int(rng.integers(1, 40))
     pipe = D.Pipeline(H, W, T.to_cfg(D, ocfg), batch=B, slots=slots, group=group)
     if xyz:
         d_in = torch.from_numpy(np.stack([O.backproject(d, *[np.float32(v) for v in intr]) for d in depth])).to(dev)

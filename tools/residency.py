@@ -11,7 +11,7 @@ import deplex_amd as D
 from deplex_amd import _capi
 import synth
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-B, S, G = 64, 16, 8
+B, S, G = 64, int(os.environ.get("DPX_BENCH_STREAMS", 4)), 8
 K = synth.read_K(synth.TUM_K); intr = tuple(float(v) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2]))
 dev = torch.device("cuda", 0)
 d_in = [torch.from_numpy(synth.tum_stream(B, seed0=r * B).view(np.int16)).to(dev) for r in range(8)]
