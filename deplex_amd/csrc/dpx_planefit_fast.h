@@ -27,8 +27,12 @@
 
 namespace dpx {
 
+// Pixels per scheduling group of the moment loop (see CellAcc::one).  1 with two-row buffers (DPX_PF_ROWBUF) brings the
+// P = 10 kernel to 112 vector registers: four plane-fit waves then leave 64 registers per SIMD free, enough for the
+// label-expansion waves (16) and a grow wave (48) of the other groups in flight to start on a CU that is full of plane-fit
+// work — measured +3 % in the pipeline (the kernel on its own is unchanged; 121 registers = 128 allocated left none).
 #ifndef DPX_PF_GROUP
-#define DPX_PF_GROUP 2
+#define DPX_PF_GROUP 1
 #endif
 #ifndef DPX_PF_WAVES
 #define DPX_PF_WAVES 4
@@ -315,6 +319,51 @@ struct PfGroup {
 #else
 #define DPX_PF_VGPR_ATTR
 #endif
+// Rows two at a time, every row index static: rows R, R+1 are in `a`, rows R+2, R+3 are fetched into `b` before `a` is
+// evaluated, then the roles swap (no copies).  Two-row buffers instead of four-row ones keep the kernel at <= 120
+// vector registers (see k_planefit_depth).
+template <int P, int R>
+struct PairRows {
+  template <class ACC>
+  static __device__ __forceinline__ void run(ACC& acc, const uint16_t* src, long long row_stride, uint32_t (&a)[2][P / 2],
+                                             uint32_t (&b)[2][P / 2], const float (&cxj)[P], int row0, const Params& prm,
+                                             float rx, float ry) {
+    if (R + 2 < P) load_cell_row<P>(src + static_cast<long long>(R + 2) * row_stride, b[0]);
+    if (R + 3 < P) load_cell_row<P>(src + static_cast<long long>(R + 3) * row_stride, b[1]);
+    acc.template row<R & 3, R>(a[0], cxj, static_cast<float>(row0 + R) - prm.cy, false, prm, rx, ry);
+    if (R + 1 < P) acc.template row<(R + 1) & 3, (R + 1 < P ? R + 1 : 0)>(a[1], cxj, static_cast<float>(row0 + R + 1) - prm.cy, false, prm, rx, ry);
+    if (R + 2 < P) PairRows<P, (R + 2 < P ? R + 2 : P)>::run(acc, src, row_stride, b, a, cxj, row0, prm, rx, ry);
+  }
+};
+template <int P>
+struct PairRows<P, P> {
+  template <class ACC>
+  static __device__ __forceinline__ void run(ACC&, const uint16_t*, long long, uint32_t (&)[2][P / 2], uint32_t (&)[2][P / 2],
+                                             const float (&)[P], int, const Params&, float, float) {}
+};
+
+// The same with one-row buffers: row R is in `a`, row R+1 is fetched into `b` before `a` is evaluated.
+template <int P, int R>
+struct SingleRows {
+  template <class ACC>
+  static __device__ __forceinline__ void run(ACC& acc, const uint16_t* src, long long row_stride, uint32_t (&a)[P / 2],
+                                             uint32_t (&b)[P / 2], const float (&cxj)[P], int row0, const Params& prm, float rx,
+                                             float ry) {
+    if (R + 1 < P) load_cell_row<P>(src + static_cast<long long>(R + 1) * row_stride, b);
+    acc.template row<R & 3, R>(a, cxj, static_cast<float>(row0 + R) - prm.cy, false, prm, rx, ry);
+    if (R + 1 < P) SingleRows<P, (R + 1 < P ? R + 1 : P)>::run(acc, src, row_stride, b, a, cxj, row0, prm, rx, ry);
+  }
+};
+template <int P>
+struct SingleRows<P, P> {
+  template <class ACC>
+  static __device__ __forceinline__ void run(ACC&, const uint16_t*, long long, uint32_t (&)[P / 2], uint32_t (&)[P / 2],
+                                             const float (&)[P], int, const Params&, float, float) {}
+};
+
+#ifndef DPX_PF_ROWBUF
+#define DPX_PF_ROWBUF 2
+#endif
 template <int P, bool FASTDIV, int DIAG>
 __device__ __forceinline__ void pf_depth_task(Params prm, const PfGroup& grp, dpx_cell* __restrict__ cells, const long long wave, const int lane) {
   static_assert(P % 2 == 0 && P >= 2, "even patch sizes only");
@@ -352,6 +401,26 @@ __device__ __forceinline__ void pf_depth_task(Params prm, const PfGroup& grp, dp
   CellAcc<P, FASTDIV, (P * P <= 256)> acc;
   acc.init();
 
+  constexpr bool kPairs = DPX_PF_ROWBUF == 2 && DIAG != 2 && P >= 2;
+  constexpr bool kSingles = DPX_PF_ROWBUF == 1 && DIAG != 2;
+  if constexpr (kSingles) {
+    uint32_t a[DW], b[DW];
+    load_cell_row<P>(src, a);
+    {
+      const uint32_t wv = a[(P / 2) / 2];
+      acc.vprev = static_cast<float>(((P / 2) & 1) ? (wv >> 16) : (wv & 0xFFFFu));  // k = P/2 -> (i = 0, j = P/2)
+    }
+    SingleRows<P, 0>::run(acc, src, static_cast<long long>(prm.W), a, b, cxj, row0, prm, rx, ry);
+  } else if constexpr (kPairs) {
+    uint32_t a[2][DW], b[2][DW];
+    load_cell_row<P>(src, a[0]);
+    if (1 < P) load_cell_row<P>(src + static_cast<long long>(prm.W), a[1]);
+    {
+      const uint32_t wv = a[0][(P / 2) / 2];
+      acc.vprev = static_cast<float>(((P / 2) & 1) ? (wv >> 16) : (wv & 0xFFFFu));  // k = P/2 -> (i = 0, j = P/2)
+    }
+    PairRows<P, 0>::run(acc, src, static_cast<long long>(prm.W), a, b, cxj, row0, prm, rx, ry);
+  } else {
   // group buffers: `cur` holds the 4 rows being processed, `nxt` the 4 rows in flight behind them
   uint32_t cur[4][DW], nxt[4][DW];
 #pragma unroll
@@ -417,6 +486,7 @@ __device__ __forceinline__ void pf_depth_task(Params prm, const PfGroup& grp, dp
     if (R0 + 3 < P) acc.template row<(R0 + 3) & 3, R0 + 3 < P ? R0 + 3 : 0>(cur[3], cxj, static_cast<float>(row0 + R0 + 3) - prm.cy, false, prm, rx, ry);
     static_assert(P - R0 <= 4, "at most one partial group after the rolled loop");
   }
+  }  // !kPairs
 
   if (A2 > 0 && n == A2) { acc.sx.fold(); acc.sy.fold(); acc.sz.fold(); }
   DPX_PF_STAMP(1)
@@ -478,6 +548,9 @@ __device__ __forceinline__ void pf_depth_task(Params prm, const PfGroup& grp, dp
 template <int P, bool FASTDIV, int DIAG = 0>
 __global__ __launch_bounds__(256, DPX_PF_WAVES) DPX_PF_VGPR_ATTR void k_planefit_depth(Params prm, PfGroup grp, dpx_cell* __restrict__ cells) {
   WaveTrace trace_(TK_PLANEFIT);
+#ifdef DPX_PF_PAD128
+  asm volatile("" ::: "v127");  // A/B switch: make the kernel allocate the full 128 registers
+#endif
   const long long wave = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
   if (wave >= static_cast<long long>(prm.batch) * prm.nv * ((prm.nh + 63) >> 6)) return;
   pf_depth_task<P, FASTDIV, DIAG>(prm, grp, cells, wave, threadIdx.x & 63);
