@@ -428,7 +428,7 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   } else if (h->regions_tier == 1 && h->regions_split && !h->d_dbg) {
     hipLaunchKernelGGL((dpx::k_regions2<1, false, 1>), dim3(batch), dim3(dpx::kRT), h->lds2_p1, s, prm, rb, rx);
     hipLaunchKernelGGL((dpx::k_regions2<1, false, 2>), dim3(batch), dim3(64), h->lds2_p2, s, prm, rb, rx);
-    hipLaunchKernelGGL((dpx::k_regions2<1, false, 3>), dim3(batch), dim3(dpx::kRT), h->lds2_p3, s, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<1, false, 3>), dim3(batch), dim3(dpx::kTailRT), h->lds2_p3, s, prm, rb, rx);
   } else if (h->regions_tier == 2 && h->d_dbg)
     hipLaunchKernelGGL((dpx::k_regions2<2, true, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
   else if (h->regions_tier == 1 && h->d_dbg)
@@ -440,9 +440,9 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
     if (h->opt_prep_v1)
       hipLaunchKernelGGL((dpx::k_regions2<2, false, 1>), dim3(batch), dim3(dpx::kRT), h->lds2_p1, s, prm, rb, rx);
     else
-      hipLaunchKernelGGL(dpx::k_region_prep, dim3(batch), dim3(dpx::kRT), h->lds2_p1, s, prm, rb, rx);
+      hipLaunchKernelGGL(dpx::k_region_prep, dim3(batch), dim3(dpx::kPrepRT), h->lds2_p1, s, prm, rb, rx);
     if (!skip_p2) hipLaunchKernelGGL((dpx::k_regions2<2, false, 2>), dim3(batch), dim3(64), h->lds2_p2, s, prm, rb, rx);
-    if (!skip_p3) hipLaunchKernelGGL((dpx::k_regions2<2, false, 3>), dim3(batch), dim3(dpx::kRT), h->lds2_p3, s, prm, rb, rx);
+    if (!skip_p3) hipLaunchKernelGGL((dpx::k_regions2<2, false, 3>), dim3(batch), dim3(dpx::kTailRT), h->lds2_p3, s, prm, rb, rx);
   } else if (h->regions_tier == 2)
     hipLaunchKernelGGL((dpx::k_regions2<2, false, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
   else if (h->regions_tier == 1)
