@@ -193,19 +193,25 @@ int prepare_intrinsics(dpx_handle h, float fx, float fy, float cx, float cy, dpx
   return DPX_OK;
 }
 
+constexpr int kPfBlockWaves = 4;
 template <int P>
 void launch_planefit_fast(const dpx::Params& prm, const dpx::PfGroup& grp, dpx_cell* d_cells, hipStream_t s, bool fastdiv) {
   const long long waves = static_cast<long long>(prm.batch) * prm.nv * ((prm.nh + 63) / 64);
-  const unsigned blocks = static_cast<unsigned>((waves + 3) / 4);
+  // waves per workgroup (a wave is a task on its own; the kernel takes any whole number of waves up to 8).  4 = one wave
+  // per SIMD is the balance point in the pipeline: single-wave workgroups fill every gap and crowd the region launches
+  // out (plane fit -20 %, regions +15 %, total -4 %), 8-wave ones are crowded out themselves (-5 %).
+  static const int wpb = std::getenv("DPX_PF_BLOCK_WAVES") ? std::max(1, std::min(8, std::atoi(std::getenv("DPX_PF_BLOCK_WAVES")))) : kPfBlockWaves;
+  const unsigned blocks = static_cast<unsigned>((waves + wpb - 1) / wpb);
+  const dim3 bd(64u * wpb);
   static const int diag = std::getenv("DPX_PF_DIAG") ? std::atoi(std::getenv("DPX_PF_DIAG")) : 0;
   if (P == 10 && diag == 1)
-    hipLaunchKernelGGL((dpx::k_planefit_depth<10, true, 1>), dim3(blocks), dim3(256), 0, s, prm, grp, d_cells);
+    hipLaunchKernelGGL((dpx::k_planefit_depth<10, true, 1>), dim3(blocks), bd, 0, s, prm, grp, d_cells);
   else if (P == 10 && diag == 2)
-    hipLaunchKernelGGL((dpx::k_planefit_depth<10, true, 2>), dim3(blocks), dim3(256), 0, s, prm, grp, d_cells);
+    hipLaunchKernelGGL((dpx::k_planefit_depth<10, true, 2>), dim3(blocks), bd, 0, s, prm, grp, d_cells);
   else if (fastdiv)
-    hipLaunchKernelGGL((dpx::k_planefit_depth<P, true>), dim3(blocks), dim3(256), 0, s, prm, grp, d_cells);
+    hipLaunchKernelGGL((dpx::k_planefit_depth<P, true>), dim3(blocks), bd, 0, s, prm, grp, d_cells);
   else
-    hipLaunchKernelGGL((dpx::k_planefit_depth<P, false>), dim3(blocks), dim3(256), 0, s, prm, grp, d_cells);
+    hipLaunchKernelGGL((dpx::k_planefit_depth<P, false>), dim3(blocks), bd, 0, s, prm, grp, d_cells);
 }
 
 template <bool DEPTH>

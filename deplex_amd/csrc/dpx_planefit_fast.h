@@ -546,12 +546,12 @@ __device__ __forceinline__ void pf_depth_task(Params prm, const PfGroup& grp, dp
 // tried, to keep part of the register file free for the other groups' region workgroups: it made no difference in the
 // pipeline, and the loop around the body cost 119 scalar and 36 vector register spills.)
 template <int P, bool FASTDIV, int DIAG = 0>
-__global__ __launch_bounds__(256, DPX_PF_WAVES) DPX_PF_VGPR_ATTR void k_planefit_depth(Params prm, PfGroup grp, dpx_cell* __restrict__ cells) {
+__global__ __launch_bounds__(512, DPX_PF_WAVES) DPX_PF_VGPR_ATTR void k_planefit_depth(Params prm, PfGroup grp, dpx_cell* __restrict__ cells) {
   WaveTrace trace_(TK_PLANEFIT);
 #ifdef DPX_PF_PAD128
   asm volatile("" ::: "v127");  // A/B switch: make the kernel allocate the full 128 registers
 #endif
-  const long long wave = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const long long wave = static_cast<long long>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (wave >= static_cast<long long>(prm.batch) * prm.nv * ((prm.nh + 63) >> 6)) return;
   pf_depth_task<P, FASTDIV, DIAG>(prm, grp, cells, wave, threadIdx.x & 63);
 }
