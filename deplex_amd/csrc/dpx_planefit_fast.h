@@ -120,11 +120,13 @@ struct CellAcc {
   // ZI: both pixels of one input dword
   __device__ __forceinline__ void dword(uint32_t w) {
     zsum = __builtin_amdgcn_sad_u16(w, 0u, zsum);
-    uint32_t m;  // min(depth, 1) per half: the compiler expands the vector form into compares and selects
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(w), "s"(0x00010001u));
-    dpx_u16x2 h;
-    __builtin_memcpy(&h, &m, 4);
-    vcnt2 += h;
+    // min(depth, 1) per half, added to the packed counters (the compiler expands the vector form of the minimum into
+    // compares and selects).  Volatile: left to itself the scheduler computes the minima of several rows' dwords at
+    // once, as soon as their loads are back, and keeps them in registers until the additions (30 registers at the peak).
+    uint32_t m, vc;
+    __builtin_memcpy(&vc, &vcnt2, 4);
+    asm volatile("v_pk_min_u16 %1, %2, %3\n\tv_pk_add_u16 %0, %0, %1" : "+v"(vc), "=&v"(m) : "v"(w), "s"(0x00010001u));
+    __builtin_memcpy(&vcnt2, &vc, 4);
   }
   __device__ __forceinline__ bool continuous(int max_disc) const {  // (at most P discontinuities per scan: no carry)
     return (static_cast<int>(disc & 0xFFFFu) < max_disc) && (static_cast<int>(disc >> 16) < max_disc);
@@ -332,6 +334,7 @@ struct PairRows {
     if (R + 3 < P) load_cell_row<P>(src + static_cast<long long>(R + 3) * row_stride, b[1]);
     acc.template row<R & 3, R>(a[0], cxj, static_cast<float>(row0 + R) - prm.cy, false, prm, rx, ry);
     if (R + 1 < P) acc.template row<(R + 1) & 3, (R + 1 < P ? R + 1 : 0)>(a[1], cxj, static_cast<float>(row0 + R + 1) - prm.cy, false, prm, rx, ry);
+    asm volatile("" ::: "memory");  // keep the following rows' loads where they are (one pair ahead, not all at the top)
     if (R + 2 < P) PairRows<P, (R + 2 < P ? R + 2 : P)>::run(acc, src, row_stride, b, a, cxj, row0, prm, rx, ry);
   }
 };
@@ -351,6 +354,7 @@ struct SingleRows {
                                              float ry) {
     if (R + 1 < P) load_cell_row<P>(src + static_cast<long long>(R + 1) * row_stride, b);
     acc.template row<R & 3, R>(a, cxj, static_cast<float>(row0 + R) - prm.cy, false, prm, rx, ry);
+    asm volatile("" ::: "memory");
     if (R + 1 < P) SingleRows<P, (R + 1 < P ? R + 1 : P)>::run(acc, src, row_stride, b, a, cxj, row0, prm, rx, ry);
   }
 };
