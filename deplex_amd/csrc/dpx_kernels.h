@@ -561,8 +561,16 @@ struct LabelOuts {
 };
 // Block b takes the (frame, cell row) tasks b, b + gridDim.x, ...: the host starts one block per CU (a few dozen blocks
 // already write at the full HBM rate; DPX_LAB_RESIDENT=0 gives one block per task).
+// Issue priority of the label-expansion waves: above the plane-fit waves they share SIMDs with (their few address / store
+// instructions then do not queue behind a saturated VALU), below the latency-bound region waves (priority 3).  +1 %.
+#ifndef DPX_LAB_PRIO
+#define DPX_LAB_PRIO 1
+#endif
 __global__ __launch_bounds__(256) void k_labels_rows(Params prm, const int32_t* __restrict__ cell_labels, LabelOuts outs, int rows_per_frame) {
  WaveTrace trace_(TK_LABELS);
+#if DPX_LAB_PRIO
+ __builtin_amdgcn_s_setprio(DPX_LAB_PRIO);
+#endif
  const int ntasks = prm.batch * rows_per_frame;
  for (int task = blockIdx.x; task < ntasks; task += gridDim.x) {
   const int frame = task / rows_per_frame;
