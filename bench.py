@@ -103,6 +103,8 @@ def main():
     # against 1.20-1.24 M with 4 slots and 1.08 M with groups of 8).  DESIGN.md section 5.
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DPX_BENCH_STREAMS", 0)), help="groups in flight (pipeline slots); 0 = auto")
     ap.add_argument("--group", type=int, default=int(os.environ.get("DPX_BENCH_GROUP", 0)), help="submissions per launch sequence (1..32); 0 = auto")
+    ap.add_argument("--flush-after", default=os.environ.get("DPX_BENCH_FLUSH_AFTER", ""),
+                    help="comma-separated step counts of the timed region after which the open group is launched early (dpx_pipeline_flush)")
     ap.add_argument("--prof-every", type=int, default=16, help="record per-kernel HIP events on every n-th slot")
     ap.add_argument("--roofline-iters", type=int, default=50)
     ap.add_argument("--no-cloud-roofline", action="store_true")
@@ -175,12 +177,15 @@ def main():
     out_ptrs = [d_labels[k].data_ptr() for k in range(S * G)]
     NB = S * G
 
+    flush_after = {int(v) for v in args.flush_after.split(",") if v.strip()}
     if d_clouds is not None:
         def step(i):
             pipe.submit_pcd(in_ptrs[i % R], B, out_ptrs[i % NB])
     else:
         def step(i):
             pipe.submit_depth(in_ptrs[i % R], B, *intr, out_ptrs[i % NB])
+            if (i + 1) in flush_after:
+                pipe.flush()
 
     def sync():
         pipe.sync()

@@ -75,6 +75,7 @@ SYMBOLS = {
     "dpx_pipeline_submit_depth": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "dpx_pipeline_submit_pcd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "dpx_pipeline_sync": (C.c_int, [C.c_void_p]),
+    "dpx_pipeline_flush": (C.c_int, [C.c_void_p]),
     "dpx_pipeline_slot": (C.c_void_p, [C.c_void_p, C.c_int32]),
     "dpx_prepare_intrinsics": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_int32)]),
     "dpx_backproject": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int32]),

@@ -1229,6 +1229,17 @@ int dpx_pipeline_sync(dpx_pipeline p) {
   return DPX_OK;
 }
 
+int dpx_pipeline_flush(dpx_pipeline p) {
+  if (!p) return fail(DPX_ERR_ARG, "null pipeline");
+  DPX_HIP(hipSetDevice(p->device));
+  for (size_t k = 0; k < p->slots.size(); ++k) {
+    const int rc = pipeline_flush(p, k);
+    if (rc) return rc;
+  }
+  p->submitted = ((p->submitted + p->group - 1) / p->group) * p->group;
+  return DPX_OK;
+}
+
 dpx_handle dpx_pipeline_slot(dpx_pipeline p, int32_t slot) {
   if (!p || slot < 0 || slot >= static_cast<int>(p->slots.size())) return nullptr;
   return p->slots[slot];

@@ -253,6 +253,10 @@ class Pipeline:
     def sync(self) -> None:
         _capi.check(_capi.lib().dpx_pipeline_sync(self._p))
 
+    def flush(self) -> None:
+        """Launch what has been submitted so far without waiting (a partially filled group goes as it is)."""
+        _capi.check(_capi.lib().dpx_pipeline_flush(self._p))
+
     def slot(self, k: int) -> "PlaneExtractor":
         """A non-owning PlaneExtractor view of slot k (result getters, profiling)."""
         h = _capi.lib().dpx_pipeline_slot(self._p, k)

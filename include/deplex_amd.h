@@ -151,6 +151,10 @@ int dpx_pipeline_submit_depth(dpx_pipeline p, const void* d_depth, int32_t batch
  * A group holds one input form; switching forms closes the open group first. */
 int dpx_pipeline_submit_pcd(dpx_pipeline p, const void* d_xyz, int32_t batch, void* d_labels);
 int dpx_pipeline_sync(dpx_pipeline p);
+/* Launches the submissions recorded so far without waiting for them (a partially filled group is launched as it is and
+ * the next submission starts a new group on the next slot).  For callers that want the first results of a stream early,
+ * or that want the groups in flight to be at different stages (short runs). */
+int dpx_pipeline_flush(dpx_pipeline p);
 dpx_handle dpx_pipeline_slot(dpx_pipeline p, int32_t slot);
 
 /* Optional: validate intrinsics ahead of the first depth call (the fused kernel divides by fx, fy through a

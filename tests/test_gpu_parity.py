@@ -550,6 +550,8 @@ def test_pipeline_group_of_many_submissions(D, oracle):
                     pipe.submit_pcd(d_cloud[i].data_ptr(), 1, d_out[i].data_ptr())
                 else:
                     pipe.submit_depth(d_depth[i].data_ptr(), 1, *intrs[i], d_out[i].data_ptr())
+                if i in (0, 3):
+                    pipe.flush()  # launches the open group early (1 and 3 submissions): the rest goes to the next slots
             pipe.sync()
             for i in range(n):
                 assert np.array_equal(d_out[i].cpu().numpy(), refs[i]), f"group {group} cloud {cloud} submission {i}"
