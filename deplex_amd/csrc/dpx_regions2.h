@@ -228,10 +228,24 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : kRT)) voi
     // bytes [16 l, 16 l + 16) of a 1 KB chunk straight into LDS, no staging registers).  All chunks of a wave are in
     // flight together and awaited once — the plain copy loop compiles to load, wait, store per KB, i.e. 32 serialized
     // memory round trips in front of the one-wave grow launch.
+    // Not everything travels: the tail reads only the header and the BFS queue — every other array of the image is dead
+    // by then or rebuilt (labels_map_, staging, plane views), so the grow launch writes back, and the tail fetches, 6 KB
+    // instead of 32 KB per 640x480 frame.  (Letting the grow launch fill the queue positions itself instead of
+    // fetching 2 C bytes of 0xFF made its wave 9 k cycles slower, for reasons not understood; not done.)
     const int nthreads = static_cast<int>(blockDim.x);
-    for (int base = tid - lane; base < img_vec; base += nthreads)  // (tid - lane: first vector of this wave's chunk)
-      if (base + lane < img_vec)
-        __builtin_amdgcn_global_load_lds((dpx_glb_ptr)(img + base + lane), (dpx_lds_ptr)(lds_v + base), 16, 0, 0);
+    const int hdr_v = 192 >> 4;
+    const int q_v0 = static_cast<int>(lay.queue >> 4), q_v1 = static_cast<int>((lay.queue + 2u * static_cast<uint32_t>(C) + 15u) >> 4);
+    auto dma = [&](int v0, int v1) {  // vectors [v0, v1) of the image, one 64-vector chunk per wave and pass
+      for (int base = v0 + (tid - lane); base < v1; base += nthreads)  // (tid - lane: first vector of this wave's chunk)
+        if (base + lane < v1)
+          __builtin_amdgcn_global_load_lds((dpx_glb_ptr)(img + base + lane), (dpx_lds_ptr)(lds_v + base), 16, 0, 0);
+    };
+    if (PHASE == 3 && !GST) {
+      dma(0, hdr_v);
+      dma(q_v0, q_v1 < img_vec ? q_v1 : img_vec);
+    } else {
+      dma(0, img_vec);
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     __syncthreads();
   }
@@ -699,7 +713,13 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : kRT)) voi
   }
   __syncthreads();
   if (PHASE == 2) {
-    for (int i = tid; i < img_vec; i += static_cast<int>(blockDim.x)) img[i] = lds_v[i];
+    if (!GST) {  // (what the tail reads: header and queue — see the image load above)
+      const int q_v0 = static_cast<int>(lay.queue >> 4), q_v1 = static_cast<int>((lay.queue + 2u * static_cast<uint32_t>(C) + 15u) >> 4);
+      for (int i = tid; i < (192 >> 4); i += static_cast<int>(blockDim.x)) img[i] = lds_v[i];
+      for (int i = q_v0 + tid; i < q_v1 && i < img_vec; i += static_cast<int>(blockDim.x)) img[i] = lds_v[i];
+    } else {
+      for (int i = tid; i < img_vec; i += static_cast<int>(blockDim.x)) img[i] = lds_v[i];
+    }
     if (rx.res && tid == 0) {
       rx.res[frame * 4 + 1] = static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - t_res;
       rx.res[frame * 4 + 3] = static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()) - t_real;  // 100 MHz ticks
@@ -1207,7 +1227,6 @@ __global__ __launch_bounds__(kPrepRT) void k_region_prep(Params prm, RegionBufs 
   unsigned char* img = reinterpret_cast<unsigned char*>(rx.lds_img + static_cast<size_t>(frame) * (rx.img_bytes >> 4));
   uint8_t* g_flags = img + lay.flags;
   uint16_t* g_binof = reinterpret_cast<uint16_t*>(img + lay.binof);
-  uint16_t* g_qpos = reinterpret_cast<uint16_t*>(img + lay.qpos);
   uint16_t* g_order = reinterpret_cast<uint16_t*>(img + lay.order);
   const dpx_cell* cells = rb.cells + static_cast<size_t>(frame) * C;
 
@@ -1290,7 +1309,7 @@ __global__ __launch_bounds__(kPrepRT) void k_region_prep(Params prm, RegionBufs 
         if (col_ok) {
           g_flags[c] = static_cast<uint8_t>(fl);
           g_binof[c] = static_cast<uint16_t>(bin1);
-          g_qpos[c] = static_cast<uint16_t>(0xFFFFu);
+        reinterpret_cast<uint16_t*>(img + lay.qpos)[c] = static_cast<uint16_t>(0xFFFFu);
           if (fl & F_UNASSIGNED) {
             ++planar_cnt;
             if (kb >= 0 && kb < nb) atomicAdd(&hist[kb], 1);
