@@ -314,6 +314,13 @@ def main():
                          "in_pipeline": {"avg_launch_ms": round(kms["planefit"], 4), "achieved": round(in_pipe, 1),
                                          "note": f"HIP events around the launches of the timed steps with {S} groups of {G} batches in flight (includes queueing behind / sharing with the other groups' kernels)"}},
         }
+        # the whole path against the same roofline: SURVEY 8(d) algorithmic bytes per frame (input + 4 B of label per pixel)
+        in_bpp = 12 if args.input == "cloud" else 2
+        pipe_gbs = fps / world * N * (in_bpp + 4) / 1e9  # per GPU
+        out["pipeline_roofline"] = {"bound": "hbm", "algorithmic_bytes_per_frame": N * (in_bpp + 4), "achieved": round(pipe_gbs, 1),
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pipe_gbs / HBM_PEAK_GBS, 4),
+                                    "note": "whole pipeline, input -> labels, per GPU; measured L2<->memory traffic is 2.48 MB per frame "
+                                            "(cell records and region images between the launches; profiles/r02e_pipeline_traffic.txt)"}
         if cloud_ms:
             out["roofline_cloud_input"] = {"kernel": "k_planefit_cloud_lds (organised xyz cloud -> per-cell moments + eigen plane fit), "
                                                      f"one launch per group of {G} submissions = {G * B} frames",
