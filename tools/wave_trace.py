@@ -19,7 +19,7 @@ import deplex_amd as D
 from deplex_amd import _capi
 import synth
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
-B, S, G = 64, 16, 8
+B, S, G = 64, int(os.environ.get("DPX_BENCH_STREAMS", 4)), 8
 K = synth.read_K(synth.TUM_K); intr = tuple(float(v) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2]))
 dev = torch.device("cuda", 0)
 d_in = [torch.from_numpy(synth.tum_stream(B, seed0=r * B).view(np.int16)).to(dev) for r in range(8)]
@@ -53,7 +53,7 @@ _, cu_idx = np.unique(cu_id, return_inverse=True)
 ncu = cu_idx.max() + 1
 simd_idx = cu_idx * 4 + simd
 names = {1: "planefit", 2: "prep", 3: "grow", 4: "tail", 5: "labels"}
-vg = {1: 128, 2: 56, 3: 56, 4: 112, 5: 16}
+vg = {1: 112, 2: 64, 3: 48, 4: 112, 5: 16}  # allocated vector registers per wave (blocks of 8)
 lds = {2: 29.6, 3: 32.6, 4: 32.6}
 T0, T1 = st.min(), en.max()
 w0, w1 = T0 + (T1 - T0) // 4, T1 - (T1 - T0) // 4
@@ -86,10 +86,11 @@ for t in ts:
         m = (pf_cu >= lo) & (pf_cu <= hi)
         joint[a, 0] += m.sum(); joint[a, 1] += reg_cu[m].sum(); joint[a, 2] += per_cu_lds[m].sum()
     vfree = (512 - per_simd_vg).reshape(ncu, 4); wfree = (8 - per_simd_w).reshape(ncu, 4); lfree = 160 - per_cu_lds
-    can_pf += np.mean((vfree >= 128).all(1) & (wfree >= 1).all(1))
-    can_prep += np.mean((vfree >= 112).all(1) & (wfree >= 2).all(1) & (lfree >= 29.6))
-    can_tail += np.mean((vfree >= 224).all(1) & (wfree >= 2).all(1) & (lfree >= 32.6))
-    can_grow += np.mean((vfree >= 56).any(1) & (wfree >= 1).any(1) & (lfree >= 32.6))
+    # (workgroups of one wave per SIMD: plane fit 4 x 112, preparation 4 x 64, tail 4 x 112; grow one wave of 48)
+    can_pf += np.mean((vfree >= 112).all(1) & (wfree >= 1).all(1))
+    can_prep += np.mean((vfree >= 64).all(1) & (wfree >= 1).all(1) & (lfree >= 29.6))
+    can_tail += np.mean((vfree >= 112).all(1) & (wfree >= 1).all(1) & (lfree >= 32.6))
+    can_grow += np.mean((vfree >= 48).any(1) & (wfree >= 1).any(1) & (lfree >= 32.6))
 ns = len(ts)
 print("time-averaged resident waves per SIMD: " + ", ".join(f"{names[k]} {acc_w[k].mean() / ns:.2f}" for k in names))
 print(f"VGPR file in use {vg_use.mean() / ns / 512 * 100:.0f} %, LDS in use {lds_use.mean() / ns / 160 * 100:.0f} %")
