@@ -73,6 +73,8 @@ struct dpx_handle_s {
   int regions_tier = -1;  // k_regions2<TIER>: 2 all state in LDS, 1 lean, 0 flags in LDS + global queues; -1 = k_regions (v1)
   size_t lds2_bytes = 0;                     // single-launch form: image + the larger of staging / sort keys
   size_t lds2_img = 0, lds2_p1 = 0, lds2_p2 = 0, lds2_p3 = 0;  // split form: image, and the three launches' allocations
+  size_t lds2_p4 = 0;                        // fused preparation + grow launch (tier 2)
+  bool opt_prep_grow_fused = false;
   int sort_pad = 0;                          // tier 2: slots of the in-LDS seed-list sort (power of two >= C)
   // variant switches, read from the environment at create (tests and diagnostics)
   bool opt_nofuse = false, opt_labels_v1 = false, opt_cloud_nolds = false, opt_prep_v1 = false;
@@ -443,11 +445,15 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
     hipLaunchKernelGGL((dpx::k_regions2<0, true, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
   else if (h->regions_tier == 2 && h->regions_split) {
     const bool skip_p2 = skip && std::strchr(skip, '2'), skip_p3 = skip_p2 || (skip && std::strchr(skip, '3'));
-    if (h->opt_prep_v1)
-      hipLaunchKernelGGL((dpx::k_regions2<2, false, 1>), dim3(batch), dim3(dpx::kRT), h->lds2_p1, s, prm, rb, rx);
-    else
-      hipLaunchKernelGGL(dpx::k_region_prep, dim3(batch), dim3(dpx::kPrepRT), h->lds2_p1, s, prm, rb, rx);
-    if (!skip_p2) hipLaunchKernelGGL((dpx::k_regions2<2, false, 2>), dim3(batch), dim3(64), h->lds2_p2, s, prm, rb, rx);
+    if (h->opt_prep_grow_fused && !skip_p2) {
+      hipLaunchKernelGGL((dpx::k_regions2<2, false, 4>), dim3(batch), dim3(dpx::kPrepRT), h->lds2_p4, s, prm, rb, rx);
+    } else {
+      if (h->opt_prep_v1)
+        hipLaunchKernelGGL((dpx::k_regions2<2, false, 1>), dim3(batch), dim3(dpx::kRT), h->lds2_p1, s, prm, rb, rx);
+      else
+        hipLaunchKernelGGL(dpx::k_region_prep, dim3(batch), dim3(dpx::kPrepRT), h->lds2_p1, s, prm, rb, rx);
+      if (!skip_p2) hipLaunchKernelGGL((dpx::k_regions2<2, false, 2>), dim3(batch), dim3(64), h->lds2_p2, s, prm, rb, rx);
+    }
     if (!skip_p3) hipLaunchKernelGGL((dpx::k_regions2<2, false, 3>), dim3(batch), dim3(dpx::kTailRT), h->lds2_p3, s, prm, rb, rx);
   } else if (h->regions_tier == 2)
     hipLaunchKernelGGL((dpx::k_regions2<2, false, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
@@ -744,7 +750,10 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
   h->opt_nofuse = std::getenv("DPX_FUSED_LABELS") == nullptr;  // fusing the label expansion into the region tail measured 3-5 % slower
   h->opt_labels_v1 = std::getenv("DPX_LABELS_V1") != nullptr;
   h->opt_cloud_nolds = std::getenv("DPX_CLOUD_NOLDS") != nullptr;
-  h->opt_prep_v1 = std::getenv("DPX_PREP_V1") != nullptr;  // test hook: tier-2 preparation with the whole image in LDS
+  h->opt_prep_v1 = std::getenv("DPX_PREP_V1") != nullptr;
+  // preparation and grow in one launch (tier 2, lean preparation, C small enough for its key hand-over; +1 % in long runs,
+  // +2.5 % in 20-step ones); DPX_PREP_GROW_SPLIT restores the two launches (test hook)
+  h->opt_prep_grow_fused = !h->opt_prep_v1 && static_cast<long long>(C) <= dpx::kFusedMaxCells && !std::getenv("DPX_PREP_GROW_SPLIT");  // test hook: tier-2 preparation with the whole image in LDS
   if (const char* e = std::getenv("DPX_CSR_CHUNK")) {  // test hook: force the wide-row walk of the merge phase
     const int v = std::atoi(e);
     h->opt_csr_chunk = v < 0 ? 0 : (v > 64 ? 64 : v);
@@ -775,6 +784,7 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
         h->lds2_p1 = h->opt_prep_v1 ? l2.image_end + 8 * pad2 : dpx::r2_prep_lds_bytes(l2, Ci);
         h->lds2_p2 = l2.image_end;
         h->lds2_p3 = l2.tail_end;
+        h->lds2_p4 = dpx::r2_fused_lds_bytes(l2, Ci);
         h->lds2_bytes = std::max<size_t>(l2.tail_end, l2.image_end + 8 * pad2);
       } else if (C < 65000 && l1.tail_end <= kLdsLimit && !want_gst) {
         h->regions_tier = 1;
@@ -877,6 +887,10 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
         if (need[i] > 48 * 1024 &&
             hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(need[i])) != hipSuccess)
           rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
+      if (rc == DPX_OK && h->regions_tier == 2 && h->lds2_p4 > 48 * 1024 &&
+          hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<2, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(h->lds2_p4)) != hipSuccess)
+        rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
     }
   }
   if (rc == DPX_OK && h->regions_tier >= 0 && h->lds2_bytes > 48 * 1024) {

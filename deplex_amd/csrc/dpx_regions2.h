@@ -162,23 +162,30 @@ struct Regions2Extra {
 //   0 = only the flag byte in LDS; queue, queue positions and sorted seed lists in global memory (L2) with 32-bit
 //       indices — frames up to ~150 000 cells (3840x2160 at P = 10 has 82 944).
 // Tiers 1 and 0 take their seed lists from dpx_binsort.h (rb.order + rx.bin_off).
+//   PHASE 4 (tier 2) = the lean preparation (region_prep_body) and the grow phase in ONE launch: the waves other than wave 0
+//   end after the preparation.  A frame's grow then starts as soon as its own preparation is done instead of after the
+//   slowest preparation workgroup of the whole group, and the image does not travel through global memory in between.
+template <bool FUSED>
+__device__ __forceinline__ void region_prep_body(const Params& prm, const RegionBufs& rb, const Regions2Extra& rx, unsigned char* smem,
+                                                 const int frame, const unsigned long long t_res);
 template <int TIER, bool DBG, int PHASE>
-__global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : kRT)) void k_regions2(Params prm, RegionBufs rb, Regions2Extra rx) {
+__global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE == 4 ? kPrepRT : kRT))) void k_regions2(Params prm, RegionBufs rb, Regions2Extra rx) {
   // (inside the kernel kRT / kRW are THIS launch's workgroup size: the tail may run with fewer waves)
-  constexpr int kRT = PHASE == 3 ? dpx::kTailRT : dpx::kRT;
+  constexpr int kRT = PHASE == 3 ? dpx::kTailRT : (PHASE == 4 ? dpx::kPrepRT : dpx::kRT);
   constexpr int kRW = kRT / 64;
   constexpr bool FULL = TIER == 2;
   constexpr bool GST = TIER == 0;
   using idx_t = typename std::conditional<GST, uint32_t, uint16_t>::type;
   constexpr uint32_t kNoPos = GST ? 0xFFFFFFFFu : 0xFFFFu;
   static_assert(PHASE == 0 || TIER >= 1, "the phase-split launches need the cell labels in LDS");
-  WaveTrace trace_(PHASE == 1 ? TK_PREP : (PHASE == 2 ? TK_GROW : TK_TAIL));
+  static_assert(PHASE != 4 || (TIER == 2 && !DBG), "the fused preparation + grow launch exists for tier 2");
+  WaveTrace trace_(PHASE == 1 ? TK_PREP : ((PHASE == 2 || PHASE == 4) ? TK_GROW : TK_TAIL));
 #if DPX_REGIONS_PRIO
   __builtin_amdgcn_s_setprio(DPX_REGIONS_PRIO);  // latency-bound waves: win issue arbitration against co-resident streaming kernels
 #endif
   unsigned long long t_start = DPX_STAMP(), t_p0 = 0, t_p1 = 0, t_p2 = 0, t_p3 = 0, t_p4 = 0, t_p5 = 0;
   const unsigned long long t_res = (PHASE > 0 && rx.res) ? static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) : 0ull;
-  const unsigned long long t_real = (PHASE == 2 && rx.res) ? static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()) : 0ull;
+  const unsigned long long t_real = ((PHASE == 2 || PHASE == 4) && rx.res) ? static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()) : 0ull;
   unsigned long long a_argmax = 0, a_seed = 0, a_bfs = 0, a_rem = 0, n_steps = 0;
   const int frame = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -223,7 +230,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : kRT)) voi
   float4* lds_v = reinterpret_cast<float4*>(smem);
   float4* img = rx.lds_img + static_cast<size_t>(frame) * (rx.img_bytes >> 4);
   const int img_vec = rx.img_bytes >> 4;
-  if (PHASE >= 2) {
+  if (PHASE == 2 || PHASE == 3) {
     // continue from the previous launch's LDS image: gfx950 LDS-DMA (global_load_lds_dwordx4: lane l of a wave delivers
     // bytes [16 l, 16 l + 16) of a 1 KB chunk straight into LDS, no staging registers).  All chunks of a wave are in
     // flight together and awaited once — the plain copy loop compiles to load, wait, store per KB, i.e. 32 serialized
@@ -248,6 +255,10 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : kRT)) voi
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     __syncthreads();
+  }
+  if constexpr (PHASE == 4) {
+    region_prep_body<true>(prm, rb, rx, smem, frame, t_res);
+    if (wid != 0) return;  // (the grow phase is wave 0's; the others give their registers and wave slots back)
   }
   if (PHASE <= 1) {
   // ---------------- P0: state into LDS, histogram, bin-grouped order ------------------------------------
@@ -412,7 +423,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : kRT)) voi
 
   // ---------------- P1: seeds + region growing, wave 0 only ---------------------------------------------
   // cursor[b] holds the END of bin b's sorted cell list; bin_start[b] the position of its first possibly live entry.
-  if ((PHASE == 0 || PHASE == 2) && (GST || wid == 0)) {
+  if ((PHASE == 0 || PHASE == 2 || PHASE == 4) && (GST || wid == 0)) {
     // Tier 0 keeps all waves in this loop: wave 0 runs the grows exactly like the other tiers, the rest wait at the
     // per-grow barrier and join when a BFS queue gets wide (>= kWideSlots pending cells): then every wave takes 16
     // consecutive queue slots of a batch, appends in (wave, lane) order through per-wave counts, and the FIFO order
@@ -712,11 +723,12 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : kRT)) voi
     }
   }
   __syncthreads();
-  if (PHASE == 2) {
+  if (PHASE == 2 || PHASE == 4) {
     if (!GST) {  // (what the tail reads: header and queue — see the image load above)
       const int q_v0 = static_cast<int>(lay.queue >> 4), q_v1 = static_cast<int>((lay.queue + 2u * static_cast<uint32_t>(C) + 15u) >> 4);
-      for (int i = tid; i < (192 >> 4); i += static_cast<int>(blockDim.x)) img[i] = lds_v[i];
-      for (int i = q_v0 + tid; i < q_v1 && i < img_vec; i += static_cast<int>(blockDim.x)) img[i] = lds_v[i];
+      const int nthr = PHASE == 4 ? 64 : static_cast<int>(blockDim.x);  // (fused launch: only wave 0 is left)
+      for (int i = tid; i < (192 >> 4); i += nthr) img[i] = lds_v[i];
+      for (int i = q_v0 + tid; i < q_v1 && i < img_vec; i += nthr) img[i] = lds_v[i];
     } else {
       for (int i = tid; i < img_vec; i += static_cast<int>(blockDim.x)) img[i] = lds_v[i];
     }
@@ -1202,29 +1214,34 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : kRT)) voi
 __host__ __device__ inline uint32_t r2_prep_keys_offset(const R2Layout& L) { return (L.flags + 7u) & ~7u; }
 __host__ __device__ inline uint32_t r2_prep_lds_bytes(const R2Layout& L, int C) { return r2_prep_keys_offset(L) + 8u * static_cast<uint32_t>(C); }
 
-__global__ __launch_bounds__(kPrepRT) void k_region_prep(Params prm, RegionBufs rb, Regions2Extra rx) {
+// FUSED = the body runs in front of the grow phase in ONE launch (k_regions2<2, ., 4>): the per-cell arrays go to the
+// LDS image instead of the image in global memory, and the sort keys lie over the image's queue-position / queue / seed-list
+// arrays (written only after the sort) and 2 C bytes behind it.
+__host__ __device__ inline uint32_t r2_fused_keys_offset(const R2Layout& L) { return (L.qpos + 7u) & ~7u; }
+__host__ __device__ inline uint32_t r2_fused_lds_bytes(const R2Layout& L, int C) {
+  const uint32_t k = r2_fused_keys_offset(L) + 8u * static_cast<uint32_t>(C);
+  return ((k > L.image_end ? k : L.image_end) + 15u) & ~15u;
+}
+constexpr int kFusedKeysPerThread = 32;
+constexpr int kFusedMaxCells = kPrepRT * kFusedKeysPerThread;
+template <bool FUSED>
+__device__ __forceinline__ void region_prep_body(const Params& prm, const RegionBufs& rb, const Regions2Extra& rx, unsigned char* smem,
+                                                 const int frame, const unsigned long long t_res) {
   constexpr int kRT = dpx::kPrepRT;  // (this launch's workgroup size)
   constexpr int kRW = kRT / 64;
-  WaveTrace trace_(TK_PREP);
-#if DPX_REGIONS_PRIO
-  __builtin_amdgcn_s_setprio(DPX_REGIONS_PRIO);
-#endif
-  const unsigned long long t_res = rx.res ? static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) : 0ull;
-  const int frame = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int C = prm.C, nh = prm.nh, nv = prm.nv;
   const int nb = prm.hist_B * prm.hist_B;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  extern __shared__ __align__(16) unsigned char smem[];
   const R2Layout lay = r2_layout(2, C, nb, nh);
   int* hdr = reinterpret_cast<int*>(smem);
   int* hist = reinterpret_cast<int*>(smem + lay.hist);
   int* cursor = reinterpret_cast<int*>(smem + lay.cursor);
   uint16_t* bin_start = reinterpret_cast<uint16_t*>(smem + lay.bin_start);
   uint16_t* nzlist = reinterpret_cast<uint16_t*>(smem + lay.nzlist);
-  unsigned long long* skeys = reinterpret_cast<unsigned long long*>(smem + r2_prep_keys_offset(lay));
+  unsigned long long* skeys = reinterpret_cast<unsigned long long*>(smem + (FUSED ? r2_fused_keys_offset(lay) : r2_prep_keys_offset(lay)));
   // the frame's image in global memory, same byte offsets as the LDS image of the grow / tail launches
-  unsigned char* img = reinterpret_cast<unsigned char*>(rx.lds_img + static_cast<size_t>(frame) * (rx.img_bytes >> 4));
+  unsigned char* img = FUSED ? smem : reinterpret_cast<unsigned char*>(rx.lds_img + static_cast<size_t>(frame) * (rx.img_bytes >> 4));
   uint8_t* g_flags = img + lay.flags;
   uint16_t* g_binof = reinterpret_cast<uint16_t*>(img + lay.binof);
   uint16_t* g_order = reinterpret_cast<uint16_t*>(img + lay.order);
@@ -1309,7 +1326,7 @@ __global__ __launch_bounds__(kPrepRT) void k_region_prep(Params prm, RegionBufs 
         if (col_ok) {
           g_flags[c] = static_cast<uint8_t>(fl);
           g_binof[c] = static_cast<uint16_t>(bin1);
-        reinterpret_cast<uint16_t*>(img + lay.qpos)[c] = static_cast<uint16_t>(0xFFFFu);
+          if (!FUSED) reinterpret_cast<uint16_t*>(img + lay.qpos)[c] = static_cast<uint16_t>(0xFFFFu);  // (FUSED: the keys lie there)
           if (fl & F_UNASSIGNED) {
             ++planar_cnt;
             if (kb >= 0 && kb < nb) atomicAdd(&hist[kb], 1);
@@ -1401,6 +1418,26 @@ __global__ __launch_bounds__(kPrepRT) void k_region_prep(Params prm, RegionBufs 
     }
     __syncthreads();
   }
+  if (FUSED) {
+    // the seed lists and the queue positions overwrite the key area: all keys go through registers first (the host
+    // takes the fused launch only for C <= kFusedMaxCells = kPrepRT * kFusedKeysPerThread)
+    uint16_t v[kFusedKeysPerThread];
+#pragma unroll
+    for (int q = 0; q < kFusedKeysPerThread; ++q) {
+      const int i = q * kRT + tid;
+      v[q] = i < n ? static_cast<uint16_t>(skeys[i] & ((1u << kKeyCellBits) - 1u)) : static_cast<uint16_t>(0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kFusedKeysPerThread; ++q) {
+      const int i = q * kRT + tid;
+      if (i < n) g_order[i] = v[q];
+    }
+    uint16_t* qp = reinterpret_cast<uint16_t*>(smem + lay.qpos);
+    for (int c = tid; c < C; c += kRT) qp[c] = static_cast<uint16_t>(0xFFFFu);
+    __syncthreads();
+    return;
+  }
   for (int i = tid; i < n; i += kRT) g_order[i] = static_cast<uint16_t>(skeys[i] & ((1u << kKeyCellBits) - 1u));
   // header, histogram and list bounds: the first lay.flags bytes of the image (a multiple of 4)
   {
@@ -1409,6 +1446,19 @@ __global__ __launch_bounds__(kPrepRT) void k_region_prep(Params prm, RegionBufs 
     for (int i = tid; i < static_cast<int>(lay.flags >> 2); i += kRT) d32[i] = s32[i];
   }
   if (rx.res && tid == 0) rx.res[frame * 4 + 0] = static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - t_res;
+}
+
+
+// (8 waves per SIMD asked for = at most 64 vector registers: one preparation wave then fits next to four plane-fit waves
+// of 112; left alone the compiler takes 71 = 72 allocated, which does not)
+__global__ __launch_bounds__(kPrepRT, 8) void k_region_prep(Params prm, RegionBufs rb, Regions2Extra rx) {
+  WaveTrace trace_(TK_PREP);
+#if DPX_REGIONS_PRIO
+  __builtin_amdgcn_s_setprio(DPX_REGIONS_PRIO);
+#endif
+  const unsigned long long t_res = rx.res ? static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) : 0ull;
+  extern __shared__ __align__(16) unsigned char smem[];
+  region_prep_body<false>(prm, rb, rx, smem, static_cast<int>(blockIdx.x), t_res);
 }
 
 }  // namespace dpx

@@ -245,7 +245,7 @@ def test_ragged_and_tiny_images(D, oracle):
                     del os.environ[env]
 
 
-@pytest.mark.parametrize("env", ["DPX_FORCE_GLOBAL_STATE", "DPX_REGIONS_V1", "DPX_REGIONS_LEAN", "DPX_REGIONS_GSTATE", "DPX_NO_FASTDIV", "DPX_PLANEFIT_V1", "DPX_LABELS_V1", "DPX_REGIONS_NOSPLIT", "DPX_FUSED_LABELS", "DPX_PREP_V1"])
+@pytest.mark.parametrize("env", ["DPX_FORCE_GLOBAL_STATE", "DPX_REGIONS_V1", "DPX_REGIONS_LEAN", "DPX_REGIONS_GSTATE", "DPX_NO_FASTDIV", "DPX_PLANEFIT_V1", "DPX_LABELS_V1", "DPX_REGIONS_NOSPLIT", "DPX_FUSED_LABELS", "DPX_PREP_V1", "DPX_PREP_GROW_SPLIT"])
 def test_kernel_variants(D, oracle, env):
     """Every kernel variant must give the same bits: region growing with its per-cell state in global memory
     (used when a frame does not fit LDS), the v1 single-wave kernel, the lean LDS tier and the flag-byte-only tier (both
