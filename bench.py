@@ -319,8 +319,8 @@ def main():
         pipe_gbs = fps / world * N * (in_bpp + 4) / 1e9  # per GPU
         out["pipeline_roofline"] = {"bound": "hbm", "algorithmic_bytes_per_frame": N * (in_bpp + 4), "achieved": round(pipe_gbs, 1),
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pipe_gbs / HBM_PEAK_GBS, 4),
-                                    "note": "whole pipeline, input -> labels, per GPU; measured L2<->memory traffic is 2.48 MB per frame "
-                                            "(cell records and region images between the launches; profiles/r02e_pipeline_traffic.txt)"}
+                                    "note": "whole pipeline, input -> labels, per GPU; measured L2<->memory traffic is 2.42 MB per frame "
+                                            "(cell records and region images between the launches; profiles/r02f_pipeline_traffic.txt)"}
         if cloud_ms:
             out["roofline_cloud_input"] = {"kernel": "k_planefit_cloud_lds (organised xyz cloud -> per-cell moments + eigen plane fit), "
                                                      f"one launch per group of {G} submissions = {G * B} frames",
