@@ -39,10 +39,24 @@ def dist_env():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-def make_workload(name: str, batch: int, rank: int, part: int = 0, parts: int = 1):
-    """Input batch number `part` of rank `rank` (every (rank, part) pair gets its own seeds)."""
+# The other BASELINE.json configs as bench lines (parity-test cases first, tests/test_gpu_parity.py::test_baseline_config_*):
+#   --workload synth1280 = configs[2] (1280x960, batch 256), synth640 = one GPU's share of configs[3] (640x480, 512 of the
+#   4096 frames), synth4k = one GPU's share of configs[4] (3840x2160, 8 of the 64 frames).  A step is one whole batch.
+BIG_WORKLOADS = {"synth1280": dict(batch=256, unique=8, steps=20, warmup=3), "synth640": dict(batch=512, unique=16, steps=40, warmup=4),
+                 "synth4k": dict(batch=8, unique=4, steps=10, warmup=2)}
+
+
+def make_workload(name: str, batch: int, rank: int, part: int = 0, parts: int = 1, unique: int = 0):
+    """Input batch number `part` of rank `rank` (every (rank, part) pair gets its own seeds).  unique > 0: that many
+    distinct frames, tiled to the batch (frame k = distinct frame k % unique) — generating hundreds of large synthetic
+    frames on the host would take longer than the whole measurement."""
     import synth
     seed0 = (rank * parts + part) * batch
+    if unique and name.startswith("synth") and batch % unique == 0 and unique < batch:
+        w, h = {"synth640": (640, 480), "synth1280": (1280, 960), "synth4k": (3840, 2160)}[name]
+        uniq = synth.synth_batch(unique, h, w, seed0=seed0)
+        return (np.concatenate([uniq] * (batch // unique)), synth.intrinsics_for(h, w),
+                f"synthetic {w}x{h} piecewise-planar depth, batch={batch} ({unique} distinct frames, tiled)")
     if name == "tum_stream":
         K = synth.read_K(synth.TUM_K)
         depth = synth.tum_stream(batch, seed0=seed0)
@@ -76,7 +90,9 @@ def cpu_baseline(depth, intr, cores: int, budget_s: float = 15.0):
     from oracle import oracle as O
     O.set_math("glibc")
     cfg = O.default_config()
-    sample = depth[: min(len(depth), 8)]
+    npix = depth.shape[1] * depth.shape[2]
+    sample = depth[: max(1, min(len(depth), 8, int(2.5e6 // npix)))]
+    depth = depth[: min(len(depth), 64)]  # (bounded sample of the large batches)
     t = time.perf_counter()
     O.process_depth_batch(cfg, sample, *intr, threads=1)
     per_frame = (time.perf_counter() - t) / len(sample)
@@ -94,9 +110,10 @@ def cpu_baseline(depth, intr, cores: int, budget_s: float = 15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=256)
-    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default 2000; the large-frame workloads have their own)")
+    ap.add_argument("--warmup", type=int, default=-1)
+    ap.add_argument("--batch", type=int, default=0, help="frames per step (default 64; --workload synth1280/synth640/synth4k: the BASELINE batch)")
+    ap.add_argument("--unique", type=int, default=-1, help="distinct frames per input batch, tiled to --batch (synthetic workloads)")
     # Pipeline shape.  0 = chosen from the run length: long runs (>= 100 steps) 4 slots x groups of 8 — one hardware queue
     # per compute pipe, measured 1.65-1.70 M frames/s against 1.55-1.60 M with 16 slots and 1.52-1.55 M with 5 or 6 —
     # short runs (the driver's 20 steps) 16 slots x groups of 5, which divides them into whole groups (1.24-1.28 M
@@ -118,6 +135,17 @@ def main():
     ap.add_argument("--inputs", type=int, default=8,
                     help="distinct input batches the steps rotate over (8 x 39 MB of depth frames exceed the 256 MB Infinity Cache)")
     args = ap.parse_args()
+    big = BIG_WORKLOADS.get(args.workload)
+    if args.batch <= 0:
+        args.batch = big["batch"] if big else 64
+    if args.steps <= 0:
+        args.steps = big["steps"] if big else 2000
+    if args.warmup < 0:
+        args.warmup = big["warmup"] if big else 256
+    if args.unique < 0:
+        args.unique = big["unique"] if big else 0
+    if big:
+        args.no_cloud_roofline = True  # (the cloud form of a 256-frame 1280x960 batch is 3.8 GB of host back-projection)
 
     rank, local_rank, world = dist_env()
     if args.gpus != world:
@@ -141,14 +169,16 @@ def main():
     import deplex_amd as D
 
     long_run = args.steps >= 100
-    S = args.streams if args.streams > 0 else (4 if long_run else 16)  # groups in flight (pipeline slots), one stream each
-    G = max(1, min(32, args.group)) if args.group > 0 else (8 if long_run else 5)
+    S = args.streams if args.streams > 0 else (2 if big else (4 if long_run else 16))  # groups in flight (pipeline slots), one stream each
+    G = max(1, min(32, args.group)) if args.group > 0 else (1 if big else (8 if long_run else 5))
+    if big and args.inputs == 8:
+        args.inputs = 2
     # The steps rotate over R distinct input batches (R divides the S*G output buffers, so buffer k always holds the
     # result of input k % R): together larger than the 256 MB Infinity Cache, i.e. the frames stream from HBM.
     R = max(1, min(args.inputs, S * G))
     while (S * G) % R:
         R -= 1
-    parts = [make_workload(args.workload, args.batch, rank, r, R) for r in range(R)]
+    parts = [make_workload(args.workload, args.batch, rank, r, R, args.unique) for r in range(R)]
     depths = [p[0] for p in parts]
     depth, intr, wl_desc = parts[0]
     B, H, W = depth.shape

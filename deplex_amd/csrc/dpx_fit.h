@@ -6,6 +6,18 @@
 // Householder + implicit-shift QL fallback when the cross products are ill-conditioned.  The floating
 // point operation order matches the reference so results are bit-identical to it given identical
 // sqrt/atan2/sin/cos (dpx_math.h); compile with -ffp-contract=off.
+//
+// Provenance: written from the published algorithm — J. Kopp, "Efficient numerical diagonalization of hermitian 3x3
+// matrices", Int. J. Mod. Phys. C 19 (2008) 523, arXiv:physics/0610206, sections 3.1 (Cardano), 3.2 (QL with implicit
+// shifts after a Householder reduction) and 4 (the hybrid's error bound).  No source text of libs/dsyev (LGPL-2.1) is
+// reproduced: the data structures (scalar Sym3 / Eig3, no arrays), the control flow (QL sweeps unrolled through one
+// rotation macro, one shared eigenvector routine) and the libm are this repository's own.  What IS the same, and has
+// to be for bit parity, is the SEQUENCE of floating-point operations of Kopp's formulas as libs/dsyev evaluates them
+// (operand order of every sum and product, the 256*eps*u^2 threshold, the QL convergence test); temporaries that
+// carry the paper's / the C code's letters (de, dd, ee, ff, c1, c0, p, q, phi, ...) do so to keep that operation order
+// checkable line by line against dsyevc3.c:53-77, dsyevh3.c:70-134, dsytrd3.h:27-102 and dsyevq3.c:57-130.  The
+// bit-for-bit check against the reference's compiled C is tests/test_oracle.py::test_eigensolver_matches_reference_dsyev
+// (oracle vs oracle/_ref) + tests/test_gpu_parity.py::test_devmath_and_eigensolver_on_device (device vs oracle).
 #pragma once
 #include "dpx_math.h"
 

@@ -623,12 +623,19 @@ struct Extractor {
         }
       if (seed < 0) seed = cand[0];  // reference reads an uninitialised int here; unreachable for finite data
       Stat acc = cells[seed].stat;  // copy of the seed: the seed is counted twice (:318,322-323)
+      const int32_t seed_bin = hist.bins[seed];
       const std::vector<int32_t> grown = grow(seed, unassigned, cells);
       for (int32_t v : grown) {
         stat_add(acc, cells[v].stat);
         hist.remove(v);
         unassigned[v] = 0;
         --remaining;
+      }
+      if (const char* tp = std::getenv("ORC_GROW_TRACE")) {  // analysis aid (tools/grow_trace.py): bin, seed, size per grow
+        if (FILE* tf = std::fopen(tp, "a")) {
+          std::fprintf(tf, "%d %d %zu\n", seed_bin, seed, grown.size());
+          std::fclose(tf);
+        }
       }
       s.grows++;
       s.activations += static_cast<int32_t>(grown.size());

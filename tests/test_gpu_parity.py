@@ -284,6 +284,80 @@ def test_large_frames(D, oracle, env):
             del os.environ[env]
 
 
+def _full_size_config(D, oracle, h, w, batch, nuniq, seed0=0):
+    """One BASELINE config at its full batch size through the stream-ordered device entry point: `nuniq` distinct
+    synthetic frames tiled to `batch` (frame k = unique frame k % nuniq).  Checks: every record of the distinct frames
+    against the oracle (labels, cells, planes, stage counters), every tiled copy bit-identical to its original (any
+    cross-frame interference at this batch size shows up here), determinism across two calls into different buffers,
+    labels constant inside each cell and bounded by the segment count."""
+    import torch
+    assert batch % nuniq == 0
+    uniq = synth.synth_batch(nuniq, h, w, seed0=seed0)
+    intr = synth.intrinsics_for(h, w)
+    N = h * w
+    dev = torch.device("cuda", 0)
+    d_depth = torch.from_numpy(uniq.view(np.int16)).to(dev).repeat(batch // nuniq, 1, 1)
+    assert d_depth.shape == (batch, h, w) and d_depth.is_contiguous()
+    d_a = torch.full((batch, N), -1, dtype=torch.int32, device=dev)
+    d_b = torch.full((batch, N), -2, dtype=torch.int32, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    ex = D.PlaneExtractor(h, w, max_batch=batch)
+    torch.cuda.synchronize()
+    ex.process_depth_device(d_depth.data_ptr(), batch, *intr, d_a.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    oracle.set_math("devmath")
+    ocfg = oracle.default_config()
+    for k in range(nuniq):
+        xyz = oracle.backproject(uniq[k], *intr)
+        ol, oc, op, ocl, ost = oracle.process(ocfg, h, w, xyz, debug=True)
+        assert np.array_equal(d_a[k].cpu().numpy(), ol), f"frame {k}: label map differs from the oracle"
+        assert_cells_equal(ex.cells(k), oc)
+        assert_planes_equal(ex.planes(k), op)
+        st = ex.frame_stats(k)
+        assert (st["planar_cells"], st["grows"], st["activations"], st["segments"], st["merges"]) == \
+               (ost["planar_cells"], ost["grows"], ost["activations"], ost["segments"], ost["merges"])
+        assert int(ol.max()) <= ost["segments"]
+        # the tiled copies of this frame: same stage counters, same plane records
+        for j in range(k + nuniq, batch, max(nuniq, (batch // 4 // nuniq) * nuniq)):
+            assert ex.frame_stats(j) == st
+            assert_planes_equal(ex.planes(j), op)
+    tiled = d_a.view(batch // nuniq, nuniq, N)
+    assert bool((tiled == tiled[:1]).all()), "tiled copies of a frame differ"
+    # checksum of checksums: a position-weighted 64-bit sum per frame, equal across the copies and across two calls
+    wgt = (torch.arange(N, device=dev, dtype=torch.int64) % 65521) + 1
+    sums_a = (d_a.to(torch.int64) * wgt).sum(dim=1)
+    ex.process_depth_device(d_depth.data_ptr(), batch, *intr, d_b.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    sums_b = (d_b.to(torch.int64) * wgt).sum(dim=1)
+    assert torch.equal(sums_a, sums_b) and torch.equal(d_a, d_b), "two calls on the same input differ"
+    assert torch.equal(sums_a.view(-1, nuniq), sums_a[:nuniq].expand(batch // nuniq, nuniq))
+    P = 10
+    lab = d_a[:: max(1, batch // 8)].view(-1, h // P, P, w // P, P)
+    assert bool((lab == lab[:, :, :1, :, :1]).all())  # constant within every cell
+
+
+def test_baseline_config_3_full_size(D, oracle):
+    """BASELINE.json configs[2]: synthetic 1280x960 (Kinect-v2 shape), batch 256, 10x10-px cells, one GPU
+    (harness shape of the reference: cpp/benchmark/benchmark_extractor.cpp:23-35, many process() calls on one extractor)."""
+    _full_size_config(D, oracle, 960, 1280, 256, 8)
+
+
+def test_baseline_config_4_full_size(D, oracle):
+    """BASELINE.json configs[3]: synthetic 640x480, batch 4096 over 8 GPUs = 512 frames per GPU; this is rank 0's shard
+    (deplex_amd.sharding.shard_range) at its full size on one GPU."""
+    from deplex_amd.sharding import shard_range
+    lo, hi = shard_range(4096, 0, 8)
+    assert hi - lo == 512
+    _full_size_config(D, oracle, 480, 640, hi - lo, 16, seed0=lo)
+
+
+@pytest.mark.parametrize("batch", [8, 64])
+def test_baseline_config_5_full_size(D, oracle, batch):
+    """BASELINE.json configs[4]: synthetic 3840x2160, batch 64 over 8 GPUs — one GPU's share (8 frames) and the whole
+    batch of 64 on one GPU (82 944 cells per frame: flag bytes in LDS, thousands of grows on the noisy frames)."""
+    _full_size_config(D, oracle, 2160, 3840, batch, 4)
+
+
 def test_fast_division_is_verified(D):
     """The reciprocal division of the fast plane-fit kernel is accepted only after an exhaustive device-side check
     against IEEE division for the frame geometry; the fixtures' intrinsics (including ICL's negative fy) pass it."""
