@@ -17,7 +17,7 @@
 // carry the paper's / the C code's letters (de, dd, ee, ff, c1, c0, p, q, phi, ...) do so to keep that operation order
 // checkable line by line against dsyevc3.c:53-77, dsyevh3.c:70-134, dsytrd3.h:27-102 and dsyevq3.c:57-130.  The
 // bit-for-bit check against the reference's compiled C is tests/test_oracle.py::test_eigensolver_matches_reference_dsyev
-// (oracle vs oracle/_ref) + tests/test_gpu_parity.py::test_devmath_and_eigensolver_on_device (device vs oracle).
+// (CPU restatement vs the reference C code built by its Makefile) + tests/test_gpu_parity.py::test_devmath_and_eigensolver_on_device (device vs oracle).
 #pragma once
 #include "dpx_math.h"
 
