@@ -777,26 +777,27 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
     if (!(v1 && v1[0] == '1') && !(force && force[0] == '1') && nb < 4600) {
       const int Ci = static_cast<int>(C), nbi = static_cast<int>(nb);
       const dpx::R2Layout l2 = dpx::r2_layout(2, Ci, nbi, nh), l1 = dpx::r2_layout(1, Ci, nbi, nh), l0 = dpx::r2_layout(0, Ci, nbi, nh);
-      if (C < 65000 && std::max<size_t>(l2.tail_end, l2.image_end + 8 * pad2) <= kLdsLimit && !want_lean && !want_gst) {
+      // (grow_end: the grow phase's scratch behind the image, see r2_layout)
+      if (C < 65000 && std::max<size_t>(std::max<size_t>(l2.tail_end, l2.grow_end), l2.image_end + 8 * pad2) <= kLdsLimit && !want_lean && !want_gst) {
         h->regions_tier = 2;
         h->sort_pad = static_cast<int>(pad2);
         h->lds2_img = l2.image_end;
         h->lds2_p1 = h->opt_prep_v1 ? l2.image_end + 8 * pad2 : dpx::r2_prep_lds_bytes(l2, Ci);
-        h->lds2_p2 = l2.image_end;
+        h->lds2_p2 = l2.grow_end;
         h->lds2_p3 = l2.tail_end;
-        h->lds2_p4 = dpx::r2_fused_lds_bytes(l2, Ci);
-        h->lds2_bytes = std::max<size_t>(l2.tail_end, l2.image_end + 8 * pad2);
-      } else if (C < 65000 && l1.tail_end <= kLdsLimit && !want_gst) {
+        h->lds2_p4 = std::max<size_t>(dpx::r2_fused_lds_bytes(l2, Ci), l2.grow_end);
+        h->lds2_bytes = std::max<size_t>(std::max<size_t>(l2.tail_end, l2.grow_end), l2.image_end + 8 * pad2);
+      } else if (C < 65000 && std::max<size_t>(l1.tail_end, l1.grow_end) <= kLdsLimit && !want_gst) {
         h->regions_tier = 1;
         h->lds2_img = l1.image_end;
         h->lds2_p1 = l1.image_end;
-        h->lds2_p2 = l1.image_end;
+        h->lds2_p2 = l1.grow_end;
         h->lds2_p3 = l1.tail_end;
-        h->lds2_bytes = l1.tail_end;
-      } else if (C < (size_t(1) << dpx::kKeyCellBits) && l0.tail_end <= kLdsLimit) {
+        h->lds2_bytes = std::max<size_t>(l1.tail_end, l1.grow_end);
+      } else if (C < (size_t(1) << dpx::kKeyCellBits) && std::max<size_t>(l0.tail_end, l0.grow_end) <= kLdsLimit) {
         h->regions_tier = 0;
         h->lds2_img = l0.image_end;
-        h->lds2_bytes = l0.tail_end;
+        h->lds2_bytes = std::max<size_t>(l0.tail_end, l0.grow_end);
       }
     }
     if (h->regions_tier == 1 || h->regions_tier == 0) {
@@ -1074,12 +1075,12 @@ int dpx_prepare_intrinsics(dpx_handle h, float fx, float fy, float cx, float cy,
   return rc;
 }
 
-int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_t* out16) {
+int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_t* out24) {
   if (!h) return fail(DPX_ERR_ARG, "null handle");
   DPX_HIP(hipSetDevice(h->device));
   if (enable && !h->d_dbg) {
-    DPX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_dbg), static_cast<size_t>(h->max_batch) * 16 * sizeof(unsigned long long)));
-    DPX_HIP(hipMemset(h->d_dbg, 0, static_cast<size_t>(h->max_batch) * 16 * sizeof(unsigned long long)));
+    DPX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_dbg), static_cast<size_t>(h->max_batch) * dpx::kDbgSlots * sizeof(unsigned long long)));
+    DPX_HIP(hipMemset(h->d_dbg, 0, static_cast<size_t>(h->max_batch) * dpx::kDbgSlots * sizeof(unsigned long long)));
     if (h->lds2_bytes > 48 * 1024 && h->regions_tier >= 0) {
       const void* fn = h->regions_tier == 2   ? reinterpret_cast<const void*>(dpx::k_regions2<2, true, 0>)
                        : h->regions_tier == 1 ? reinterpret_cast<const void*>(dpx::k_regions2<1, true, 0>)
@@ -1087,10 +1088,10 @@ int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_
       DPX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds2_bytes)));
     }
   }
-  if (out16) {
+  if (out24) {
     if (!h->d_dbg || frame < 0 || frame >= h->max_batch) return fail(DPX_ERR_ARG, "diagnostics not enabled or bad frame");
     DPX_HIP(hipStreamSynchronize(h->last_stream));
-    DPX_HIP(hipMemcpy(out16, h->d_dbg + static_cast<size_t>(frame) * 16, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    DPX_HIP(hipMemcpy(out24, h->d_dbg + static_cast<size_t>(frame) * dpx::kDbgSlots, dpx::kDbgSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   }
   if (!enable && h->d_dbg) {
     hipFree(h->d_dbg);

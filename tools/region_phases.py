@@ -23,8 +23,12 @@ _capi.check(_capi.lib().dpx_debug_region_phases(ex._h, 1, 0, None))
 for rep in range(2):
     ex.process_depth_batch(depth, *intr)
 names = ["P0 load", "P1 seeds+bfs", "P2 accum", "P3 fits", "P4 labels", "P5 merge", "P6 final", "total",
-         "sum argmax", "sum seed", "sum bfs", "sum removal", "bfs steps", "grows", "cands", "activations"]
+         "sum argmax", "sum seeds+spec", "sum bfs", "rounds|spec_grows<<32", "bfs steps", "grows", "cands", "activations",
+         "cyc scans", "cyc spec", "lane scan steps", "wave scan steps", "spec pops",
+         "stops: large grow", "stops: bin touched", "stops: cell taken"]
 for f in (range(B) if B <= 8 else sorted(set((0, 1, B - 1)))):
-    out = np.zeros(16, dtype=np.uint64)
+    out = np.zeros(24, dtype=np.uint64)
     _capi.check(_capi.lib().dpx_debug_region_phases(ex._h, 1, f, out.ctypes.data))
-    print(f"frame {f}: " + ", ".join(f"{n}={int(v)}" for n, v in zip(names, out)), "stats", ex.frame_stats(f))
+    vals = [int(v) for v in out]
+    txt = ", ".join(f"{n}={v}" for n, v in zip(names, vals) if not n.startswith("rounds"))
+    print(f"frame {f}: {txt}, sweep rounds={vals[11] & 0xFFFFFFFF}, grows committed by rounds={vals[11] >> 32}", "stats", ex.frame_stats(f))
