@@ -96,7 +96,7 @@ struct R2Layout {
 // first live entry of every bin's seed list, bclaim[nb] = lowest lane of a sweep round that takes a cell of the bin
 // (exact: a bin that lost a cell is SKIPPED, so a hash collision must not fake one), and the hashed claim table of the
 // round's cells (a collision there only ends a round early).
-__host__ __device__ constexpr int claim_bits(int tier) { return tier == 2 ? 9 : 12; }
+__host__ __device__ constexpr int claim_bits(int) { return 12; }
 // Tier 0 keeps the BFS queue in global memory; the last 2^kRingBits entries are mirrored in an LDS ring, which is where
 // the BFS reads its batch from (a batch is at most 128 entries behind the tail unless the frontier is wider than the ring).
 constexpr int kRingBits = 13;
@@ -134,7 +134,8 @@ __host__ __device__ inline R2Layout r2_layout(int tier, int C, int nb, int nh) {
     L.tail_end = L.image_end + stage_bytes;
   }
   L.grow_x = L.image_end;
-  L.grow_end = L.grow_x + 8u * static_cast<uint32_t>(nb) + (4u << claim_bits(tier)) + (tier == 0 ? (4u << kRingBits) : 0u);
+  L.grow_end = tier == 2 ? L.grow_x  // (tier 2 grows event by event: no scratch)
+                         : L.grow_x + 8u * static_cast<uint32_t>(nb) + (4u << claim_bits(tier)) + (tier == 0 ? (4u << kRingBits) : 0u);
   return L;
 }
 
@@ -153,7 +154,7 @@ struct Regions2Extra {
   int frames_per_out;       // frame f writes to labels_out[f / frames_per_out] (grouped submissions have one buffer each)
 };
 
-constexpr int kDbgSlots = 24;  // words per frame of the diagnostic instantiation's output
+constexpr int kDbgSlots = 32;  // words per frame of the diagnostic instantiation's output
 #define DPX_STAMP() (DBG ? static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) : 0ull)
 
 // DBG = true is a separate diagnostic instantiation (phase timing through s_memtime); production uses DBG = false.
@@ -181,7 +182,10 @@ template <bool FUSED>
 __device__ __forceinline__ void region_prep_body(const Params& prm, const RegionBufs& rb, const Regions2Extra& rx, unsigned char* smem,
                                                  const int frame, const unsigned long long t_res);
 template <int TIER, bool DBG, int PHASE>
-__global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE == 4 ? kPrepRT : kRT))) void k_regions2(Params prm, RegionBufs rb, Regions2Extra rx) {
+// (the fused preparation + grow launch is held at the 72 vector registers its preparation part needs: 73 would be
+// allocated as 80, and the launch shares its CUs with the plane-fit waves of the other groups)
+// (second launch bound: 7 workgroups of kPrepRT = 256 threads per CU = 7 waves per SIMD = at most 72 registers)
+__global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE == 4 ? kPrepRT : kRT)), PHASE == 4 ? 7 : 1) void k_regions2(Params prm, RegionBufs rb, Regions2Extra rx) {
   // (inside the kernel kRT / kRW are THIS launch's workgroup size: the tail may run with fewer waves)
   constexpr int kRT = PHASE == 3 ? dpx::kTailRT : (PHASE == 4 ? dpx::kPrepRT : dpx::kRT);
   constexpr int kRW = kRT / 64;
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
   unsigned long long t_start = DPX_STAMP(), t_p0 = 0, t_p1 = 0, t_p2 = 0, t_p3 = 0, t_p4 = 0, t_p5 = 0;
   const unsigned long long t_res = (PHASE > 0 && rx.res) ? static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) : 0ull;
   const unsigned long long t_real = ((PHASE == 2 || PHASE == 4) && rx.res) ? static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()) : 0ull;
-  unsigned long long a_argmax = 0, a_seed = 0, a_bfs = 0, a_rem = 0, n_steps = 0, n_spec = 0, n_rounds = 0, n_scan1 = 0, n_scan64 = 0, a_scan = 0, a_spec = 0, n_pops = 0, n_stop_inc = 0, n_stop_bin = 0, n_stop_cell = 0;
+  unsigned long long a_argmax = 0, a_seed = 0, a_bfs = 0, a_rem = 0, n_steps = 0, n_spec = 0, n_rounds = 0, n_scan1 = 0, n_scan64 = 0, a_scan = 0, a_spec = 0, n_pops = 0, n_stop_inc = 0, n_stop_bin = 0, n_stop_cell = 0, a_claims = 0, a_commit = 0, n_fast = 0, a_fast = 0;
   const int frame = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int C = prm.C, nh = prm.nh, nv = prm.nv;
@@ -452,20 +456,22 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
 #pragma unroll
     for (int q = 0; q < 4; ++q) mybin[q] = (lane + 64 * q < nnz) ? static_cast<int>(nzlist[lane + 64 * q]) : -1;
     const int nsets = (nnz + 63) >> 6;
+    const bool reg_bins = nnz <= 256;  // (tier-2 path: otherwise the arg-max walks the list in LDS)
+    const int reg_sets = nsets;
     // grow-phase scratch (r2_layout): the cached seed of every bin and the claim table of a sweep round
     constexpr uint32_t kCandNone = 0xFFFFFFFFu, kCandBig = 0x80000000u;
     constexpr int kClaimBits = claim_bits(TIER);
-#ifndef DPX_SPEC_MAX
-#define DPX_SPEC_MAX 8
-#endif
-    constexpr int kSpecMax = DPX_SPEC_MAX;  // cells of a speculative grow (<= 8): one relative cell code per byte of a 64-bit register pair
+    constexpr int kSpecMax = 8;  // cells of a speculative grow: one relative cell code per byte of a 64-bit register pair
+    // Rounds with fewer events take the first one on its own (see there): a sweep round costs about what four single
+    // events cost, and on average 60 % of a round's events are committed before it stops.
+    constexpr int kSweepMinEvents = 6;  // cells of a speculative grow (<= 8): one relative cell code per byte of a 64-bit register pair
     uint32_t* candc = reinterpret_cast<uint32_t*>(smem + lay.grow_x);
     uint32_t* bclaim = candc + nb;
     uint32_t* ctab = bclaim + nb;
     uint32_t* ring = ctab + (1 << kClaimBits);  // tier 0 only
     constexpr uint32_t kRingMask = (1u << kRingBits) - 1u;
     auto claim_slot = [&](uint32_t k) { return (k * 2654435761u) >> (32 - kClaimBits); };
-    if (wid == 0) {
+    if (TIER != 2 && wid == 0) {
       for (int i = lane; i < nb; i += 64) {
         candc[i] = kCandNone;
         bclaim[i] = 0xFFFFFFFFu;
@@ -530,331 +536,514 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
           // loop would have done, in this order, and is committed at once: queue ranges by prefix sum, flags, histogram,
           // grow / candidate-segment records.  The first lane that is not clean waits for the next round; if it is the
           // first event of a round it can only be an incomplete (large) grow, which takes the wave-wide BFS below.
-          if (DBG) ++n_rounds;
-          // 1. level of the most frequent bin, and the first 64-bin chunk that holds a bin at that level
-          uint32_t key = 0;
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (q < nsets) {  // (uniform)
-              const uint32_t cnt = mybin[q] >= 0 ? static_cast<uint32_t>(hist[mybin[q]]) : 0u;
-              const uint32_t k = (cnt << 8) | static_cast<uint32_t>(255 - q);
-              key = k > key ? k : key;
-            }
-          for (int q = 4; q < nsets; ++q) {
-            const int t = lane + 64 * q;
-            const uint32_t cnt = t < nnz ? static_cast<uint32_t>(hist[nzlist[t]]) : 0u;
-            const uint32_t k = (cnt << 8) | static_cast<uint32_t>(255 - (q < 255 ? q : 255));
-            key = k > key ? k : key;
-          }
-          key = wave_max_u32(key);
-          const int bv = static_cast<int>(key >> 8);
-          int qc = 255 - static_cast<int>(key & 255u);
-          if (bv <= 0) break;
-          if (static_cast<unsigned long long>(bv) < static_cast<unsigned long long>(static_cast<long long>(prm.min_cand))) break;
-          if (qc >= 255)  // (more than 255 chunks: find the chunk by scanning; never with the default 400 bins)
-            for (qc = 255; qc < nsets; ++qc) {
-              const int t = lane + 64 * qc;
-              if (__ballot(t < nnz && hist[nzlist[t]] == bv)) break;
-            }
-          // 2. the events of this round: bins of chunk qc at level bv, ascending = lane order
-          int b;
-          if (qc < 4) {
-            b = mybin[0];
-            b = qc == 1 ? mybin[1] : b;
-            b = qc == 2 ? mybin[2] : b;
-            b = qc == 3 ? mybin[3] : b;
-          } else {
-            const int t = lane + 64 * qc;
-            b = t < nnz ? static_cast<int>(nzlist[t]) : -1;
-          }
-          const int bs = b >= 0 ? b : 0;
-          bool part = b >= 0 && hist[bs] == bv;
-          int pos = static_cast<int>(bin_start[bs]);
-          const int lend = cursor[bs];
-          const uint32_t cw = candc[bs];
-          tb = DPX_STAMP();
-          // 3. seeds: the first live entry of each bin's list (sorted by mse, then cell id).  candc[] caches the verified
-          // entry at bin_start[] until it is used or dies; bin_start[] only moves forward.
-          uint32_t c = cw == kCandNone ? 0u : (cw & ~kCandBig);
-          bool big = cw != kCandNone && (cw & kCandBig) != 0u;  // this seed's grow exceeded kSpecMax cells before
-          bool need = part && (cw == kCandNone || (flags[c] & F_UNASSIGNED) == 0u);
-          if (need) {
-            if (cw != kCandNone) ++pos;  // the cached entry died (activated by another bin's grow)
-            big = false;
-          }
-          bool broken = false;
-          const unsigned long long t_s0 = DPX_STAMP();
-          if (__ballot(need)) {
-            // one step per lane on its own (four entries: most dead runs are short) ...
-            if (need) {
-              if (pos >= lend) {  // cannot happen (a bin's count is the number of live entries of its list): safety net
-                broken = true;
-                need = false;
-              } else {
-                const int i1 = pos + 1 < lend ? pos + 1 : lend - 1, i2 = pos + 2 < lend ? pos + 2 : lend - 1, i3 = pos + 3 < lend ? pos + 3 : lend - 1;
-                const uint32_t e0 = order[pos], e1 = order[i1], e2 = order[i2], e3 = order[i3];
-                const uint32_t f0 = flags[e0], f1 = flags[e1], f2 = flags[e2], f3 = flags[e3];
-                if (f0 & F_UNASSIGNED) { c = e0; need = false; }
-                else if ((f1 & F_UNASSIGNED) && pos + 1 < lend) { c = e1; pos += 1; need = false; }
-                else if ((f2 & F_UNASSIGNED) && pos + 2 < lend) { c = e2; pos += 2; need = false; }
-                else if ((f3 & F_UNASSIGNED) && pos + 3 < lend) { c = e3; pos += 3; need = false; }
-                else pos += 4;
+          uint32_t seed = 0xFFFFFFFFu;
+          int bb = 0;
+          if constexpr (TIER == 2) {
+            // Small frames (<= ~8 k cells: 640x480) keep the plain sequence — arg-max, first live entry of the bin's sorted
+            // list with its isolated-seed test, grow — one event per iteration: frames with a few large planes (the TUM
+            // stream of the bench) hardly ever have several bins at the same level, a sweep round costs about what four
+            // to six single events cost, and the one-wave grow launch of the pipeline must stay small in registers.
+            // most frequent bin, lowest index among maxima: key = count << kBinBits | (kBinMask - bin)
+            constexpr int kBinBits = GST ? 13 : 16;  // tier 0: counts up to 2^19, bins < 2^13
+            constexpr uint32_t kBinMask = (1u << kBinBits) - 1u;
+            uint32_t key = 0;
+            if (reg_bins) {
+              if (mybin[0] >= 0) key = (static_cast<uint32_t>(hist[mybin[0]]) << kBinBits) | (kBinMask - static_cast<uint32_t>(mybin[0]));
+              if (reg_sets > 1) {  // uniform
+      #pragma unroll
+                for (int q = 1; q < 4; ++q) {
+                  const uint32_t k = mybin[q] >= 0 ? (static_cast<uint32_t>(hist[mybin[q]]) << kBinBits) | (kBinMask - static_cast<uint32_t>(mybin[q])) : 0u;
+                  key = k > key ? k : key;
+                }
+              }
+            } else {
+              for (int t = lane; t < nnz; t += 64) {
+                const int b = nzlist[t];
+                const uint32_t k = (static_cast<uint32_t>(hist[b]) << kBinBits) | (kBinMask - static_cast<uint32_t>(b));
+                key = k > key ? k : key;
               }
             }
-            if (DBG) ++n_scan1;
-            // ... then the wave together, bin after bin, 64 entries per step: behind a large grow the front of a list (its
-            // lowest-MSE cells) is dead for hundreds or thousands of entries
-            unsigned long long nm = __ballot(need);
-            while (nm) {
-              const int l = static_cast<int>(__builtin_ctzll(nm));
-              nm &= nm - 1ull;
-              int p = __builtin_amdgcn_readlane(pos, l);
-              const int e = __builtin_amdgcn_readlane(lend, l);
-              uint32_t found = 0xFFFFFFFFu;
-              while (p < e) {
-                const int i = p + lane;
-                uint32_t ce = 0;
-                bool alive = false;
+            key = wave_max_u32(key);
+            const int bv = static_cast<int>(key >> kBinBits);
+            bb = static_cast<int>(kBinMask - (key & kBinMask));
+            if (bv <= 0) break;
+            if (static_cast<unsigned long long>(bv) < static_cast<unsigned long long>(static_cast<long long>(prm.min_cand))) break;
+            tb = DPX_STAMP();
+            {
+              // the bin's list is sorted by (mse, cell id): the seed is its first live entry.  bin_start[bb] only moves
+              // forward (a grown cell never comes back), so every list entry is skipped at most once per frame.
+              //
+              // Isolated seeds: on noisy frames two thirds of all grows activate nothing but their seed (no neighbour is both
+              // unassigned and reachable from it).  The chunk scan reads the seed's four neighbour flags along with its own,
+              // and such a grow is committed right here — one queue slot, one grow — without a BFS step.  (Committing several
+              // in a row does not pay: the arg-max keeps the fullest bins level, so it changes bin after almost every grow.)
+              int s0 = static_cast<int>(bin_start[bb]);
+              const int e = cursor[bb];
+              const bool iso_ok = prm.min_cells > 1 || prm.min_cells < 0;  // a one-cell grow is never a segment candidate
+              bool committed = false;
+              while (s0 < e) {
+                const int i = s0 + lane;
+                uint32_t c = 0, f = 0;
+                bool alive = false, iso = false;
                 if (i < e) {
-                  ce = order[i];
-                  alive = (flags[ce] & F_UNASSIGNED) != 0u;
+                  c = order[i];
+                  const int cc = static_cast<int>(c);
+                  // (not clamped: the flag bytes are in LDS in every tier, a read outside the grid returns bytes of the
+                  // neighbouring arrays and can only make the cell look connected — see below)
+                  const int wU = cc - nh, wD = cc + nh, wL = cc - 1, wR = cc + 1;
+                  f = flags[cc];
+                  const uint32_t fU = flags[wU], fD = flags[wD], fL = flags[wL], fR = flags[wR];
+                  alive = (f & F_UNASSIGNED) != 0;
+                  // a neighbour that is unassigned and whose in-edge bit for this cell's side is set can be activated from
+                  // here; non-existent neighbours can only make a cell look connected, never isolated
+                  const uint32_t out = ((fU & (fU >> 3)) | (fD & (fD >> 2)) | (fL & (fL >> 5)) | (fR & (fR >> 4))) & 1u;
+                  iso = alive && out == 0u && iso_ok;
                 }
                 const unsigned long long am = __ballot(alive);
-                if (DBG) ++n_scan64;
                 if (am) {
-                  const int first = static_cast<int>(__builtin_ctzll(am));
-                  found = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ce), first));
-                  p += first;
+                  const int first = __builtin_ctzll(am);
+                  seed = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c), first));
+                  committed = ((__ballot(iso) >> first) & 1ull) != 0ull;
+                  if (committed && lane == first) {
+                    queue[tail] = static_cast<idx_t>(c);
+                    qpos[c] = static_cast<idx_t>(tail);
+                    flags[c] = static_cast<uint8_t>(f & ~F_UNASSIGNED);
+                    grow_start[ngrow] = static_cast<uint32_t>(tail);
+                    atomicSub(&hist[bb], 1);
+                  }
+                  s0 += first + 1;
                   break;
                 }
-                p += 64;
+                s0 += 64;
               }
-              if (lane == l) {
-                need = false;
-                pos = p;
-                if (found == 0xFFFFFFFFu) broken = true;
-                else c = found;
+              if (lane == 0) bin_start[bb] = static_cast<idx_t>(s0 < e ? s0 : e);
+              if (committed) {
+                ++tail;
+                ++ngrow;
+                --remaining;
+                wave_sync();
+                if (DBG) {
+                  const unsigned long long tc2 = DPX_STAMP();
+                  a_argmax += tb - ta; a_seed += tc2 - tb;
+                }
+                st = 0;
+                break;
               }
             }
-          }
-          if (DBG) a_scan += DPX_STAMP() - t_s0;
-          if (__ballot(broken)) break;
-          // 4. speculative grow of every event on the current mask, one lane each: exact FIFO BFS (queue order, then U, D, L,
-          // R: plane_extractor.cpp:349-392).  A cell is a relative code ((dr + 8) << 4 | (dc + 8)) in one byte, the grow a
-          // list of <= 8 bytes in two registers (entry 0 = the seed, 0x88); a BFS of <= 8 cells stays within 7 rows / columns
-          // of its seed, and an empty byte (0) matches no code.  In-edge bits make the L / R steps across a row end and the
-          // bounds test the U / D steps across the grid's first / last row fail, as in the wave-wide BFS.  A lone wave is
-          // bound by its instruction count, so the accept tests come first and the list work runs only where a lane accepts.
-          uint32_t l0 = 0x88u, l1 = 0u;
-          int n = 1, hpop = 0;
-          bool complete = !big;
-          bool act = part && !big;
-          const int cs = part ? static_cast<int>(c) : 0;
-          const unsigned long long t_sp0 = DPX_STAMP();
-          while (__ballot(act)) {
-            if (DBG) ++n_pops;
-            const uint32_t code = act ? ((hpop < 4 ? (l0 >> (8 * hpop)) : (l1 >> (8 * (hpop - 4)))) & 0xFFu) : 0x88u;
-            const int cr = static_cast<int>(code >> 4), cc = static_cast<int>(code & 15u);
-            const int u = cs + (cr - 8) * nh + (cc - 8);
-            // (unclamped reads: u is a grid cell, its neighbours' bytes lie inside the flag array or its nh guard bytes)
-            const uint32_t fU = flags[u - nh], fD = flags[u + nh], fL = flags[u - 1], fR = flags[u + 1];
-            // v accepts u iff v is unassigned and its in-edge from u's side is set (u is v's D / U / R / L neighbour)
-            const bool okU = act && u >= nh && ((fU & (fU >> 3)) & 1u) != 0u;
-            const bool okD = act && u + nh < C && ((fD & (fD >> 2)) & 1u) != 0u;
-            const bool okL = act && u >= 1 && ((fL & (fL >> 5)) & 1u) != 0u;
-            const bool okR = act && u + 1 < C && ((fR & (fR >> 4)) & 1u) != 0u;
-            auto visit = [&](bool ok, int vr, int vc) {
-              const bool far = vr == 0 || vr == 16 || vc == 0 || vc == 16;  // 8 rows / columns away: not in the list (only when n == 8)
-              const uint32_t vcode = (static_cast<uint32_t>(vr) << 4) | static_cast<uint32_t>(vc);
-              const uint32_t rep = (vcode & 0xFFu) * 0x01010101u;
-              const uint32_t x0 = l0 ^ rep, x1 = l1 ^ rep;
-              const bool dup = !far && ((((x0 - 0x01010101u) & ~x0) | ((x1 - 0x01010101u) & ~x1)) & 0x80808080u) != 0u;
-              if (ok && act && !dup) {
-                if (n == kSpecMax) {
-                  complete = false;
-                  act = false;
+            if (seed == 0xFFFFFFFFu) break;
+          } else {
+            if (DBG) ++n_rounds;
+            // 1. level of the most frequent bin, and the first 64-bin chunk that holds a bin at that level
+            uint32_t key = 0;
+            uint32_t cntq[4] = {0u, 0u, 0u, 0u};  // counts of this lane's bins (chunks 0..3)
+  #pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (q < nsets) {  // (uniform)
+                cntq[q] = mybin[q] >= 0 ? static_cast<uint32_t>(hist[mybin[q]]) : 0u;
+                const uint32_t k = (cntq[q] << 8) | static_cast<uint32_t>(255 - q);
+                key = k > key ? k : key;
+              }
+            for (int q = 4; q < nsets; ++q) {
+              const int t = lane + 64 * q;
+              const uint32_t cnt = t < nnz ? static_cast<uint32_t>(hist[nzlist[t]]) : 0u;
+              const uint32_t k = (cnt << 8) | static_cast<uint32_t>(255 - (q < 255 ? q : 255));
+              key = k > key ? k : key;
+            }
+            key = wave_max_u32(key);
+            const int bv = static_cast<int>(key >> 8);
+            int qc = 255 - static_cast<int>(key & 255u);
+            if (bv <= 0) break;
+            if (static_cast<unsigned long long>(bv) < static_cast<unsigned long long>(static_cast<long long>(prm.min_cand))) break;
+            if (qc >= 255)  // (more than 255 chunks: find the chunk by scanning; never with the default 400 bins)
+              for (qc = 255; qc < nsets; ++qc) {
+                const int t = lane + 64 * qc;
+                if (__ballot(t < nnz && hist[nzlist[t]] == bv)) break;
+              }
+            // 2. the events of this round: bins of chunk qc at level bv, ascending = lane order
+            int b;
+            bool part;
+            if (qc < 4) {
+              b = mybin[0];
+              b = qc == 1 ? mybin[1] : b;
+              b = qc == 2 ? mybin[2] : b;
+              b = qc == 3 ? mybin[3] : b;
+              uint32_t cs_ = cntq[0];
+              cs_ = qc == 1 ? cntq[1] : cs_;
+              cs_ = qc == 2 ? cntq[2] : cs_;
+              cs_ = qc == 3 ? cntq[3] : cs_;
+              part = b >= 0 && cs_ == static_cast<uint32_t>(bv);
+            } else {
+              const int t = lane + 64 * qc;
+              b = t < nnz ? static_cast<int>(nzlist[t]) : -1;
+              part = b >= 0 && hist[b >= 0 ? b : 0] == bv;
+            }
+            const int bs = b >= 0 ? b : 0;
+            tb = DPX_STAMP();
+            const unsigned long long partmask = __ballot(part);
+            const int nev = static_cast<int>(__popcll(partmask));
+            if (nev < kSweepMinEvents) {
+              // A few events only (frames with a few large planes spend most rounds here: the fullest bins differ in count).
+              // Too little to run in parallel for what a sweep round costs, so only the first event is taken, without
+              // speculation: the wave looks at the bin's list 64 entries at a time, each lane reading its entry's flag byte
+              // and the four neighbours' — the first live entry is the seed, and if no neighbour can be activated from it
+              // the grow is that single cell and is committed on the spot.
+              if (DBG) ++n_fast;
+              const int l1 = static_cast<int>(__builtin_ctzll(partmask));
+              bb = __builtin_amdgcn_readlane(b, l1);
+              int s0 = static_cast<int>(bin_start[bb]);  // (same address in every lane: one LDS broadcast)
+              const int e1 = cursor[bb];
+              bool iso1 = false;
+              while (s0 < e1) {
+                const int i = s0 + lane;
+                uint32_t ce = 0, f = 0;
+                bool alive = false, iso = false;
+                if (i < e1) {
+                  ce = order[i];
+                  const int cc = static_cast<int>(ce);
+                  f = flags[cc];
+                  const uint32_t fU = flags[cc - nh], fD = flags[cc + nh], fL = flags[cc - 1], fR = flags[cc + 1];
+                  alive = (f & F_UNASSIGNED) != 0u;
+                  // (a read outside the grid returns bytes of the neighbouring arrays: it can only make the cell look connected)
+                  iso = alive && (((fU & (fU >> 3)) | (fD & (fD >> 2)) | (fL & (fL >> 5)) | (fR & (fR >> 4))) & 1u) == 0u;
+                }
+                const unsigned long long am = __ballot(alive);
+                if (am) {
+                  const int first = static_cast<int>(__builtin_ctzll(am));
+                  seed = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ce), first));
+                  iso1 = ((__ballot(iso) >> first) & 1ull) != 0ull;
+                  s0 += first + 1;
+                  break;
+                }
+                s0 += 64;
+              }
+              if (seed == 0xFFFFFFFFu) break;  // (cannot happen: the bin's count is the number of live entries of its list)
+              if (lane == 0) {
+                bin_start[bb] = static_cast<idx_t>(s0);
+                candc[bb] = kCandNone;
+              }
+              // a one-cell grow is a segment candidate only for min_cells <= 1: those take the general path below
+              if (iso1 && (prm.min_cells > 1 || prm.min_cells < 0)) {
+                if (lane == 0) {
+                  queue[tail] = static_cast<idx_t>(seed);
+                  const int sc = static_cast<int>(seed);
+                  atomicAnd(reinterpret_cast<uint32_t*>(flags + (sc & ~3)), ~(F_UNASSIGNED << ((sc & 3) * 8)));
+                  atomicSub(&hist[bb], 1);
+                  grow_start[ngrow] = static_cast<uint32_t>(tail);
+                }
+                tail = __builtin_amdgcn_readfirstlane(tail + 1);
+                ++ngrow;
+                --remaining;
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                if (DBG) {
+                  const unsigned long long tc2 = DPX_STAMP();
+                  a_argmax += tb - ta; a_seed += tc2 - tb; a_fast += tc2 - tb;
+                  ++n_spec;
+                }
+                st = 0;
+                break;
+              }
+              asm volatile("" ::: "memory");
+              __builtin_amdgcn_wave_barrier();
+              if (DBG) a_fast += DPX_STAMP() - tb;
+            } else {
+            int pos = static_cast<int>(bin_start[bs]);
+            const int lend = cursor[bs];
+            const uint32_t cw = candc[bs];
+            // 3. seeds: the first live entry of each bin's list (sorted by mse, then cell id).  candc[] caches the verified
+            // entry at bin_start[] until it is used or dies; bin_start[] only moves forward.
+            uint32_t c = cw == kCandNone ? 0u : (cw & ~kCandBig);
+            bool big = cw != kCandNone && (cw & kCandBig) != 0u;  // this seed's grow exceeded kSpecMax cells before
+            bool need = part && (cw == kCandNone || (flags[c] & F_UNASSIGNED) == 0u);
+            if (need) {
+              if (cw != kCandNone) ++pos;  // the cached entry died (activated by another bin's grow)
+              big = false;
+            }
+            bool broken = false;
+            const unsigned long long t_s0 = DPX_STAMP();
+            if (__ballot(need)) {
+              // one step per lane on its own (four entries: most dead runs are short) ...
+              if (need) {
+                if (pos >= lend) {  // cannot happen (a bin's count is the number of live entries of its list): safety net
+                  broken = true;
+                  need = false;
                 } else {
-                  if (n < 4) l0 |= vcode << (8 * n);
-                  else l1 |= vcode << (8 * (n - 4));
-                  ++n;
+                  const int i1 = pos + 1 < lend ? pos + 1 : lend - 1, i2 = pos + 2 < lend ? pos + 2 : lend - 1, i3 = pos + 3 < lend ? pos + 3 : lend - 1;
+                  const uint32_t e0 = order[pos], e1 = order[i1], e2 = order[i2], e3 = order[i3];
+                  const uint32_t f0 = flags[e0], f1 = flags[e1], f2 = flags[e2], f3 = flags[e3];
+                  if (f0 & F_UNASSIGNED) { c = e0; need = false; }
+                  else if ((f1 & F_UNASSIGNED) && pos + 1 < lend) { c = e1; pos += 1; need = false; }
+                  else if ((f2 & F_UNASSIGNED) && pos + 2 < lend) { c = e2; pos += 2; need = false; }
+                  else if ((f3 & F_UNASSIGNED) && pos + 3 < lend) { c = e3; pos += 3; need = false; }
+                  else pos += 4;
                 }
               }
-            };
-            if (__ballot(okU)) visit(okU, cr - 1, cc);
-            if (__ballot(okD)) visit(okD, cr + 1, cc);
-            if (__ballot(okL)) visit(okL, cr, cc - 1);
-            if (__ballot(okR)) visit(okR, cr, cc + 1);
-            ++hpop;
-            if (hpop >= n) act = false;
-            // a seed whose four neighbours all join sits inside a plane: leave it to the wave-wide BFS right away (any
-            // give-up rule is exact — an incomplete grow is simply not committed from here)
-            if (act && hpop == 1 && n == 5) {
-              complete = false;
-              act = false;
+              if (DBG) ++n_scan1;
+              // ... then the wave together, bin after bin, 64 entries per step: behind a large grow the front of a list (its
+              // lowest-MSE cells) is dead for hundreds or thousands of entries
+              unsigned long long nm = __ballot(need);
+              while (nm) {
+                const int l = static_cast<int>(__builtin_ctzll(nm));
+                nm &= nm - 1ull;
+                int p = __builtin_amdgcn_readlane(pos, l);
+                const int e = __builtin_amdgcn_readlane(lend, l);
+                uint32_t found = 0xFFFFFFFFu;
+                while (p < e) {
+                  const int i = p + lane;
+                  uint32_t ce = 0;
+                  bool alive = false;
+                  if (i < e) {
+                    ce = order[i];
+                    alive = (flags[ce] & F_UNASSIGNED) != 0u;
+                  }
+                  const unsigned long long am = __ballot(alive);
+                  if (DBG) ++n_scan64;
+                  if (am) {
+                    const int first = static_cast<int>(__builtin_ctzll(am));
+                    found = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ce), first));
+                    p += first;
+                    break;
+                  }
+                  p += 64;
+                }
+                if (lane == l) {
+                  need = false;
+                  pos = p;
+                  if (found == 0xFFFFFFFFu) broken = true;
+                  else c = found;
+                }
+              }
             }
-          }
-          if (DBG) a_spec += DPX_STAMP() - t_sp0;
-          // 5. which events fire.  Rounds in which every grow is a single cell need no claims: the seeds are distinct
-          // cells of distinct bins.  Otherwise every complete lane claims its cells, and the bins of its non-seed cells,
-          // with min(lane); every lane then reads the lowest claimant of its bin (lowb) and of its cells (lowc).
-          const bool spec = part && complete;
-          const unsigned long long partmask = __ballot(part);
-          const unsigned long long multi = __ballot(spec && n > 1);
-          uint32_t lowb = 0xFFFFFFFFu, lowc = 0xFFFFFFFFu;
-          int cell[kSpecMax], cbin[kSpecMax];
-          cell[0] = cs;
-          cbin[0] = b;
-#pragma unroll
-          for (int i = 1; i < kSpecMax; ++i) {
-            cell[i] = cs;
-            cbin[i] = -1;
-          }
-          // (longest complete grow of the round, wave-uniform: the unrolled loops below stop there with a scalar test)
-          const int nmax = multi ? static_cast<int>(wave_max_u32(spec ? static_cast<uint32_t>(n) : 0u)) : 1;
-          if (multi) {
-#pragma unroll
+            if (DBG) a_scan += DPX_STAMP() - t_s0;
+            if (__ballot(broken)) break;
+            // 4. speculative grow of every event on the current mask, one lane each: exact FIFO BFS (queue order, then U, D, L,
+            // R: plane_extractor.cpp:349-392).  A cell is a relative code ((dr + 8) << 4 | (dc + 8)) in one byte, the grow a
+            // list of <= 8 bytes in two registers (entry 0 = the seed, 0x88); a BFS of <= 8 cells stays within 7 rows / columns
+            // of its seed, and an empty byte (0) matches no code.  In-edge bits make the L / R steps across a row end and the
+            // bounds test the U / D steps across the grid's first / last row fail, as in the wave-wide BFS.  A lone wave is
+            // bound by its instruction count, so the accept tests come first and the list work runs only where a lane accepts.
+            uint32_t l0 = 0x88u, l1 = 0u;
+            int n = 1, hpop = 0;
+            bool complete = !big;
+            bool act = part && !big;
+            const int cs = part ? static_cast<int>(c) : 0;
+            // How far speculation pays depends on how many events can be committed together: a pop costs about as much as a
+            // step of the wave-wide BFS (which takes 16 cells).
+            const int maxpops = nev >= 8 ? kSpecMax : (kSpecMax < 4 ? kSpecMax : 4);
+            const unsigned long long t_sp0 = DPX_STAMP();
+            while (__ballot(act)) {
+              if (DBG) ++n_pops;
+              const uint32_t code = act ? ((hpop < 4 ? (l0 >> (8 * hpop)) : (l1 >> (8 * (hpop - 4)))) & 0xFFu) : 0x88u;
+              const int cr = static_cast<int>(code >> 4), cc = static_cast<int>(code & 15u);
+              const int u = cs + (cr - 8) * nh + (cc - 8);
+              // (unclamped reads: u is a grid cell, its neighbours' bytes lie inside the flag array or its nh guard bytes)
+              const uint32_t fU = flags[u - nh], fD = flags[u + nh], fL = flags[u - 1], fR = flags[u + 1];
+              // v accepts u iff v is unassigned and its in-edge from u's side is set (u is v's D / U / R / L neighbour)
+              const bool okU = act && u >= nh && ((fU & (fU >> 3)) & 1u) != 0u;
+              const bool okD = act && u + nh < C && ((fD & (fD >> 2)) & 1u) != 0u;
+              const bool okL = act && u >= 1 && ((fL & (fL >> 5)) & 1u) != 0u;
+              const bool okR = act && u + 1 < C && ((fR & (fR >> 4)) & 1u) != 0u;
+              auto visit = [&](bool ok, int vr, int vc) {
+                const bool far = vr == 0 || vr == 16 || vc == 0 || vc == 16;  // 8 rows / columns away: not in the list (only when n == 8)
+                const uint32_t vcode = (static_cast<uint32_t>(vr) << 4) | static_cast<uint32_t>(vc);
+                const uint32_t rep = (vcode & 0xFFu) * 0x01010101u;
+                const uint32_t x0 = l0 ^ rep, x1 = l1 ^ rep;
+                const bool dup = !far && ((((x0 - 0x01010101u) & ~x0) | ((x1 - 0x01010101u) & ~x1)) & 0x80808080u) != 0u;
+                if (ok && act && !dup) {
+                  if (n == kSpecMax) {
+                    complete = false;
+                    act = false;
+                  } else {
+                    if (n < 4) l0 |= vcode << (8 * n);
+                    else l1 |= vcode << (8 * (n - 4));
+                    ++n;
+                  }
+                }
+              };
+              if (__ballot(okU)) visit(okU, cr - 1, cc);
+              if (__ballot(okD)) visit(okD, cr + 1, cc);
+              if (__ballot(okL)) visit(okL, cr, cc - 1);
+              if (__ballot(okR)) visit(okR, cr, cc + 1);
+              ++hpop;
+              if (hpop >= n) act = false;
+              if (act && hpop >= maxpops) {  // (see maxpops)
+                complete = false;
+                act = false;
+              }
+              // a seed whose four neighbours all join sits inside a plane: leave it to the wave-wide BFS right away (any
+              // give-up rule is exact — an incomplete grow is simply not committed from here)
+              if (act && hpop == 1 && n == 5) {
+                complete = false;
+                act = false;
+              }
+            }
+            if (DBG) a_spec += DPX_STAMP() - t_sp0;
+            const unsigned long long t_cl0 = DPX_STAMP();
+            // 5. which events fire.  Rounds in which every grow is a single cell need no claims: the seeds are distinct
+            // cells of distinct bins.  Otherwise every complete lane claims its cells, and the bins of its non-seed cells,
+            // with min(lane); every lane then reads the lowest claimant of its bin (lowb) and of its cells (lowc).
+            const bool spec = part && complete;
+            const unsigned long long multi = __ballot(spec && n > 1);
+            uint32_t lowb = 0xFFFFFFFFu, lowc = 0xFFFFFFFFu;
+            int cell[kSpecMax], cbin[kSpecMax];
+            cell[0] = cs;
+            cbin[0] = b;
+  #pragma unroll
             for (int i = 1; i < kSpecMax; ++i) {
-              if (i < nmax) {
-                const uint32_t code = (i < 4 ? (l0 >> (8 * i)) : (l1 >> (8 * (i - 4)))) & 0xFFu;
-                const bool have = spec && i < n;
-                cell[i] = have ? cs + (static_cast<int>(code >> 4) - 8) * nh + (static_cast<int>(code & 15u) - 8) : cs;
-                int bn = 0;
-                if (have) bn = HASBIN ? static_cast<int>(binof[cell[i]]) : static_cast<int>(meta[cell[i]] >> META_BIN_SHIFT);
-                cbin[i] = (bn - 1 < nb) ? bn - 1 : -1;
-              }
+              cell[i] = cs;
+              cbin[i] = -1;
             }
-            if (spec) atomicMin(&ctab[claim_slot(static_cast<uint32_t>(cs))], static_cast<uint32_t>(lane));
-#pragma unroll
-            for (int i = 1; i < kSpecMax; ++i)
-              if (i < nmax && spec && i < n) {
-                atomicMin(&ctab[claim_slot(static_cast<uint32_t>(cell[i]))], static_cast<uint32_t>(lane));
-                if (cbin[i] >= 0) atomicMin(&bclaim[cbin[i]], static_cast<uint32_t>(lane));
+            // (longest complete grow of the round, wave-uniform: the unrolled loops below stop there with a scalar test)
+            const int nmax = multi ? static_cast<int>(wave_max_u32(spec ? static_cast<uint32_t>(n) : 0u)) : 1;
+            if (multi) {
+  #pragma unroll
+              for (int i = 1; i < kSpecMax; ++i) {
+                if (i < nmax) {
+                  const uint32_t code = (i < 4 ? (l0 >> (8 * i)) : (l1 >> (8 * (i - 4)))) & 0xFFu;
+                  const bool have = spec && i < n;
+                  cell[i] = have ? cs + (static_cast<int>(code >> 4) - 8) * nh + (static_cast<int>(code & 15u) - 8) : cs;
+                  int bn = 0;
+                  if (have) bn = HASBIN ? static_cast<int>(binof[cell[i]]) : static_cast<int>(meta[cell[i]] >> META_BIN_SHIFT);
+                  cbin[i] = (bn - 1 < nb) ? bn - 1 : -1;
+                }
               }
-            asm volatile("" ::: "memory");  // (LDS executes a wave's operations in order; only the compiler must keep it)
-            __builtin_amdgcn_wave_barrier();
-            if (part) {  // (incomplete grows read too: whether their bin / seed is still theirs decides skip or wide BFS)
-              lowb = bclaim[b];
-              lowc = ctab[claim_slot(static_cast<uint32_t>(cs))];
-#pragma unroll
+              if (spec) atomicMin(&ctab[claim_slot(static_cast<uint32_t>(cs))], static_cast<uint32_t>(lane));
+  #pragma unroll
               for (int i = 1; i < kSpecMax; ++i)
                 if (i < nmax && spec && i < n) {
-                  const uint32_t m = ctab[claim_slot(static_cast<uint32_t>(cell[i]))];
-                  lowc = m < lowc ? m : lowc;
+                  atomicMin(&ctab[claim_slot(static_cast<uint32_t>(cell[i]))], static_cast<uint32_t>(lane));
+                  if (cbin[i] >= 0) atomicMin(&bclaim[cbin[i]], static_cast<uint32_t>(lane));
                 }
+              asm volatile("" ::: "memory");  // (LDS executes a wave's operations in order; only the compiler must keep it)
+              __builtin_amdgcn_wave_barrier();
+              if (part) {  // (incomplete grows read too: whether their bin / seed is still theirs decides skip or wide BFS)
+                lowb = bclaim[b];
+                lowc = ctab[claim_slot(static_cast<uint32_t>(cs))];
+  #pragma unroll
+                for (int i = 1; i < kSpecMax; ++i)
+                  if (i < nmax && spec && i < n) {
+                    const uint32_t m = ctab[claim_slot(static_cast<uint32_t>(cell[i]))];
+                    lowc = m < lowc ? m : lowc;
+                  }
+              }
+              asm volatile("" ::: "memory");
+              __builtin_amdgcn_wave_barrier();
+              if (spec) {  // leave the table clean for the next round
+                ctab[claim_slot(static_cast<uint32_t>(cs))] = 0xFFFFFFFFu;
+  #pragma unroll
+                for (int i = 1; i < kSpecMax; ++i)
+                  if (i < nmax && i < n) {
+                    ctab[claim_slot(static_cast<uint32_t>(cell[i]))] = 0xFFFFFFFFu;
+                    if (cbin[i] >= 0) bclaim[cbin[i]] = 0xFFFFFFFFu;
+                  }
+              }
             }
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            if (spec) {  // leave the table clean for the next round
-              ctab[claim_slot(static_cast<uint32_t>(cs))] = 0xFFFFFFFFu;
-#pragma unroll
-              for (int i = 1; i < kSpecMax; ++i)
-                if (i < nmax && i < n) {
-                  ctab[claim_slot(static_cast<uint32_t>(cell[i]))] = 0xFFFFFFFFu;
-                  if (cbin[i] >= 0) bclaim[cbin[i]] = 0xFFFFFFFFu;
+            // Lanes in order; only the flagged ones need a look.  A lane whose bin lost a cell to a lower lane THAT FIRES is no
+            // longer at level L when its turn comes: it does not fire in this sweep and is skipped.  The first lane that
+            // fires with a grow that is large, or that shares a cell with a lower lane, ends the prefix; so does any lane whose
+            // lowest claimant was itself skipped (the table keeps only the minimum: what the other claimants did is unknown).
+            const unsigned long long t_cm0 = DPX_STAMP();
+            if (DBG) a_claims += t_cm0 - t_cl0;
+            const bool flag = part && (!complete || lowb < static_cast<uint32_t>(lane) || lowc < static_cast<uint32_t>(lane));
+            unsigned long long fl = __ballot(flag), skipped = 0ull;
+            int stop = 64;
+            bool stop_wide = false;
+            while (fl) {
+              const int t = static_cast<int>(__builtin_ctzll(fl));
+              fl &= fl - 1ull;
+              const uint32_t mb = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(lowb), t));
+              const uint32_t mc = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(lowc), t));
+              const bool inc = __builtin_amdgcn_readlane(static_cast<int>(complete), t) == 0;
+              if (mb < static_cast<uint32_t>(t)) {
+                if (((skipped >> mb) & 1ull) == 0ull) {
+                  skipped |= 1ull << t;
+                  if (DBG) ++n_stop_bin;
+                  continue;
                 }
-            }
-          }
-          // Lanes in order; only the flagged ones need a look.  A lane whose bin lost a cell to a lower lane THAT FIRES is no
-          // longer at level L when its turn comes: it does not fire in this sweep and is skipped.  The first lane that
-          // fires with a grow that is large, or that shares a cell with a lower lane, ends the prefix; so does any lane whose
-          // lowest claimant was itself skipped (the table keeps only the minimum: what the other claimants did is unknown).
-          const bool flag = part && (!complete || lowb < static_cast<uint32_t>(lane) || lowc < static_cast<uint32_t>(lane));
-          unsigned long long fl = __ballot(flag), skipped = 0ull;
-          int stop = 64;
-          bool stop_wide = false;
-          while (fl) {
-            const int t = static_cast<int>(__builtin_ctzll(fl));
-            fl &= fl - 1ull;
-            const uint32_t mb = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(lowb), t));
-            const uint32_t mc = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(lowc), t));
-            const bool inc = __builtin_amdgcn_readlane(static_cast<int>(complete), t) == 0;
-            if (mb < static_cast<uint32_t>(t)) {
-              if (((skipped >> mb) & 1ull) == 0ull) {
-                skipped |= 1ull << t;
-                if (DBG) ++n_stop_bin;
-                continue;
+                stop = t;
+                break;
               }
               stop = t;
+              stop_wide = !(mc < static_cast<uint32_t>(t)) && inc;
+              if (DBG) { if (stop_wide) ++n_stop_inc; else ++n_stop_cell; }
               break;
             }
-            stop = t;
-            stop_wide = !(mc < static_cast<uint32_t>(t)) && inc;
-            if (DBG) { if (stop_wide) ++n_stop_inc; else ++n_stop_cell; }
-            break;
+            // 6. commit the lanes that fire before the stop
+            const unsigned long long cm = (stop >= 64 ? partmask : (partmask & ((1ull << stop) - 1ull))) & ~skipped;
+            const bool cmt = ((cm >> lane) & 1ull) != 0ull;
+            if (part) {  // list head and seed cache of every participating bin
+              const bool used = cmt || (stop_wide && lane == stop);
+              bin_start[b] = static_cast<idx_t>(used ? pos + 1 : pos);
+              candc[b] = used ? kCandNone : (c | ((complete && !big) ? 0u : kCandBig));
+            }
+            if (cm) {
+              const int grank = static_cast<int>(__popcll(cm & lt_mask));
+              const int ncm = static_cast<int>(__popcll(cm));
+              int base, total;
+              if (!(multi & cm)) {  // (uniform) one cell each
+                base = tail + grank;
+                total = ncm;
+              } else {
+                const int myn = cmt ? n : 0;
+                int incl = myn;  // inclusive wave scan with DPP row shifts / broadcasts
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);
+                total = __builtin_amdgcn_readlane(incl, 63);
+                base = tail + incl - myn;
+              }
+              const bool want_cand = cmt && !(static_cast<unsigned long long>(n) < static_cast<unsigned long long>(static_cast<long long>(prm.min_cells)));
+              const unsigned long long wantmask = __ballot(want_cand);
+              if (cmt) {
+                queue[base] = static_cast<idx_t>(cs);
+                // (no queue position: the BFS's pull test only needs the positions of the CURRENT batch, and a stale or
+                // absent one can never fall into it)
+                atomicAnd(reinterpret_cast<uint32_t*>(flags + (cs & ~3)), ~(F_UNASSIGNED << ((cs & 3) * 8)));
+                atomicSub(&hist[b], 1);  // hist.removePoint
+                grow_start[ngrow + grank] = static_cast<uint32_t>(base);
+              }
+              if (multi & cm) {
+  #pragma unroll
+                for (int i = 1; i < kSpecMax; ++i)
+                  if (i < nmax && cmt && i < n) {
+                    const int v = cell[i];
+                    queue[base + i] = static_cast<idx_t>(v);
+                    atomicAnd(reinterpret_cast<uint32_t*>(flags + (v & ~3)), ~(F_UNASSIGNED << ((v & 3) * 8)));
+                    if (cbin[i] >= 0) atomicSub(&hist[cbin[i]], 1);
+                  }
+              }
+              if (wantmask) {
+                const int crank = static_cast<int>(__popcll(wantmask & lt_mask));
+                if (want_cand && ncand + crank < rb.pcap)
+                  cand_grow[ncand + crank] = make_uint4(static_cast<uint32_t>(ngrow + grank), static_cast<uint32_t>(base), static_cast<uint32_t>(base + n), 0u);
+                const int nwant = static_cast<int>(__popcll(wantmask));
+                ncand += nwant < rb.pcap - ncand ? nwant : (rb.pcap - ncand > 0 ? rb.pcap - ncand : 0);
+              }
+              tail = __builtin_amdgcn_readfirstlane(tail + total);
+              ngrow += ncm;
+              remaining -= total;
+              if (DBG) n_spec += ncm;
+            }
+            // (nothing written here is read back through global memory before the tail phases' barriers: no fence)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (DBG) a_commit += DPX_STAMP() - t_cm0;
+            if (!stop_wide) {
+              if (DBG) {
+                const unsigned long long tc2 = DPX_STAMP();
+                a_argmax += tb - ta; a_seed += tc2 - tb;
+              }
+              st = 0;
+              break;
+            }
+            // the stopping event is a large grow whose bin and seed no lower lane touched: it fires now, wave-wide
+            seed = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c), stop));
+            bb = __builtin_amdgcn_readlane(b, stop);
+            }  // (several events)
           }
-          // 6. commit the lanes that fire before the stop
-          const unsigned long long cm = (stop >= 64 ? partmask : (partmask & ((1ull << stop) - 1ull))) & ~skipped;
-          const bool cmt = ((cm >> lane) & 1ull) != 0ull;
-          if (part) {  // list head and seed cache of every participating bin
-            const bool used = cmt || (stop_wide && lane == stop);
-            bin_start[b] = static_cast<idx_t>(used ? pos + 1 : pos);
-            candc[b] = used ? kCandNone : (c | ((complete && !big) ? 0u : kCandBig));
-          }
-          if (cm) {
-            const int grank = static_cast<int>(__popcll(cm & lt_mask));
-            const int ncm = static_cast<int>(__popcll(cm));
-            int base, total;
-            if (!(multi & cm)) {  // (uniform) one cell each
-              base = tail + grank;
-              total = ncm;
-            } else {
-              const int myn = cmt ? n : 0;
-              int incl = myn;  // inclusive wave scan with DPP row shifts / broadcasts
-              incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);
-              incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);
-              incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);
-              incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);
-              incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);
-              incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);
-              total = __builtin_amdgcn_readlane(incl, 63);
-              base = tail + incl - myn;
-            }
-            const bool want_cand = cmt && !(static_cast<unsigned long long>(n) < static_cast<unsigned long long>(static_cast<long long>(prm.min_cells)));
-            const unsigned long long wantmask = __ballot(want_cand);
-            if (cmt) {
-              queue[base] = static_cast<idx_t>(cs);
-              // (no queue position: the BFS's pull test only needs the positions of the CURRENT batch, and a stale or
-              // absent one can never fall into it)
-              atomicAnd(reinterpret_cast<uint32_t*>(flags + (cs & ~3)), ~(F_UNASSIGNED << ((cs & 3) * 8)));
-              atomicSub(&hist[b], 1);  // hist.removePoint
-              grow_start[ngrow + grank] = static_cast<uint32_t>(base);
-            }
-            if (multi & cm) {
-#pragma unroll
-              for (int i = 1; i < kSpecMax; ++i)
-                if (i < nmax && cmt && i < n) {
-                  const int v = cell[i];
-                  queue[base + i] = static_cast<idx_t>(v);
-                  atomicAnd(reinterpret_cast<uint32_t*>(flags + (v & ~3)), ~(F_UNASSIGNED << ((v & 3) * 8)));
-                  if (cbin[i] >= 0) atomicSub(&hist[cbin[i]], 1);
-                }
-            }
-            if (wantmask) {
-              const int crank = static_cast<int>(__popcll(wantmask & lt_mask));
-              if (want_cand && ncand + crank < rb.pcap)
-                cand_grow[ncand + crank] = make_uint4(static_cast<uint32_t>(ngrow + grank), static_cast<uint32_t>(base), static_cast<uint32_t>(base + n), 0u);
-              const int nwant = static_cast<int>(__popcll(wantmask));
-              ncand += nwant < rb.pcap - ncand ? nwant : (rb.pcap - ncand > 0 ? rb.pcap - ncand : 0);
-            }
-            tail = __builtin_amdgcn_readfirstlane(tail + total);
-            ngrow += ncm;
-            remaining -= total;
-            if (DBG) n_spec += ncm;
-          }
-          // (nothing written here is read back through global memory before the tail phases' barriers: no fence)
-          asm volatile("" ::: "memory");
-          __builtin_amdgcn_wave_barrier();
-          if (!stop_wide) {
-            if (DBG) {
-              const unsigned long long tc2 = DPX_STAMP();
-              a_argmax += tb - ta; a_seed += tc2 - tb;
-            }
-            st = 0;
-            break;
-          }
-          // the stopping event is a large grow whose bin and seed no lower lane touched: it fires now, wave-wide
-          const uint32_t seed = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c), stop));
-          const int bb = __builtin_amdgcn_readlane(b, stop);
           asm volatile("" ::: "memory");
           __builtin_amdgcn_wave_barrier();
 
@@ -1492,7 +1681,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
       d[0] = t_p0 - t_start; d[1] = t_p1 - t_p0; d[2] = t_p2 - t_p1; d[3] = t_p3 - t_p2; d[4] = t_p4 - t_p3;
       d[5] = t_p5 - t_p4; d[6] = t_end - t_p5; d[7] = t_end - t_start;
       d[8] = a_argmax; d[9] = a_seed; d[10] = a_bfs; d[11] = n_rounds | (n_spec << 32); d[12] = n_steps; d[13] = ngrow; d[14] = ncand; d[15] = activations;
-      d[16] = a_scan; d[17] = a_spec; d[18] = n_scan1; d[19] = n_scan64; d[20] = n_pops; d[21] = n_stop_inc; d[22] = n_stop_bin; d[23] = n_stop_cell;
+      d[16] = a_scan; d[17] = a_spec; d[18] = n_scan1; d[19] = n_scan64; d[20] = n_pops; d[21] = n_stop_inc; d[22] = n_stop_bin; d[23] = n_stop_cell; d[24] = a_claims; d[25] = a_commit; d[26] = n_fast; d[27] = a_fast;
     }
   }
 }

@@ -200,10 +200,11 @@ int dpx_time_planefit_group(dpx_handle h, const void* const* d_in, int32_t nsub,
 int64_t dpx_planefit_bytes(dpx_handle h, int32_t input_kind, int32_t batch);
 
 /* Diagnostic build of the region-growing kernel: shader-clock cycles per phase of frame `frame` of the last call
- * (out24, 24 words: P0 state load, P1 seeds+BFS, P2 accumulate, P3 fits, P4 labels, P5 merge, P6 final, total; sums
+ * (out24, 32 words: P0 state load, P1 seeds+BFS, P2 accumulate, P3 fits, P4 labels, P5 merge, P6 final, total; sums
  * over the sweep rounds of arg-max, seeds + speculative grows + commit, wave-wide BFS; [11] = rounds | grows committed
  * by rounds << 32; BFS steps, grows, candidates, activations; [16..20] = cycles in list scans, cycles in speculative
- * grows, per-lane scan steps, 64-entry scan steps, speculative pops).  enable != 0 switches the diagnostic
+ * grows, per-lane scan steps, 64-entry scan steps, speculative pops; [21..27] = why rounds stopped, cycles in claims /
+ * resolution + commit, rounds that took a single event and their cycles).  enable != 0 switches the diagnostic
  * instantiation on for later calls; never used when timing. */
 int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_t* out24);
 /* Diagnostic (handles created with DPX_RESIDENCY=1 in the environment): average shader-clock lifetime of a frame's
