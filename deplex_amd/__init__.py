@@ -6,5 +6,6 @@
 from . import utils  # noqa: F401
 from ._capi import DeplexError  # noqa: F401
 from .plane_extraction import Config, Pipeline, PlaneExtractor  # noqa: F401
+from .sharding import ShardedExtractor, pinned_empty, shard_range  # noqa: F401
 
-__all__ = ["Config", "PlaneExtractor", "Pipeline", "DeplexError", "utils"]
+__all__ = ["Config", "PlaneExtractor", "Pipeline", "ShardedExtractor", "pinned_empty", "shard_range", "DeplexError", "utils"]

@@ -70,6 +70,7 @@ struct dpx_handle_s {
   bool regions_split = false;
   float* d_mse_c = nullptr;
   uint32_t* d_cand_grow = nullptr;
+  bool no_pixel_labels = false;  // set for the duration of a cell-level call: the label expansion launch is left out
   int regions_tier = -1;  // k_regions2<TIER>: 2 all state in LDS, 1 lean, 0 flags in LDS + global queues; -1 = k_regions (v1)
   size_t lds2_bytes = 0;                     // single-launch form: image + the larger of staging / sort keys
   size_t lds2_img = 0, lds2_p1 = 0, lds2_p2 = 0, lds2_p3 = 0;  // split form: image, and the three launches' allocations
@@ -83,6 +84,8 @@ struct dpx_handle_s {
   unsigned long long* d_sort_keys = nullptr;  // [B][Cpad]
   uint32_t* d_bin_off = nullptr;              // [B][nb + 1]
   uint32_t* d_gqpos = nullptr;                // tier 0: [B][C]
+  dpx_plane* d_pack = nullptr;                // cell-level output: the batch's plane records packed back to back
+  int32_t* d_pack_counts = nullptr;           // [max_batch] counts + 8-byte total
   uint8_t* d_gflags = nullptr;
   uint8_t* d_gowner = nullptr;
   uint32_t* d_gqueue = nullptr;
@@ -123,6 +126,8 @@ void free_all(dpx_handle h) {
   hipFree(h->d_meta);
   hipFree(h->d_order);
   hipFree(h->d_grow_start);
+  if (h->d_pack) hipFree(h->d_pack);
+  if (h->d_pack_counts) hipFree(h->d_pack_counts);
   hipFree(h->d_cand);
   hipFree(h->d_planes);
   hipFree(h->d_cell_labels);
@@ -421,7 +426,7 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   rb.merge = h->d_merge; rb.stats = h->d_stats; rb.g_flags = h->d_gflags; rb.g_owner = h->d_gowner;
   rb.g_queue = h->d_gqueue; rb.pcap = h->pcap;
   // the region kernel's tail can write the pixel label map itself (no separate label-expansion launch)
-  const bool fuse_labels = (h->regions_tier == 2 || h->regions_tier == 1) && (prm.W & 3) == 0 && !h->opt_nofuse && !skip_l && !skip_r;
+  const bool fuse_labels = (h->regions_tier == 2 || h->regions_tier == 1) && (prm.W & 3) == 0 && !h->opt_nofuse && !skip_l && !skip_r && !h->no_pixel_labels;
   dpx::Regions2Extra rx{};
   rx.mse_c = h->d_mse_c; rx.cand_grow = h->d_cand_grow; rx.dbg = h->d_dbg; rx.lds_img = h->d_lds_img;
   rx.res = h->d_res;
@@ -468,7 +473,7 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   if (prof) DPX_HIP(hipEventRecord(ev[4], s));
   // ---- label expansion (per sub-batch: each has its own output buffer)
   if (prof) DPX_HIP(hipEventRecord(ev[5], s));
-  if (!skip_l && !fuse_labels) {
+  if (!skip_l && !fuse_labels && !h->no_pixel_labels) {
     const bool labels_v1 = h->opt_labels_v1;
     if ((prm.W & 3) == 0 && prm.nv + 1 <= 65535 && !labels_v1) {
       // one launch for the whole group: block (frame, cell row) finds its output buffer through `outs`
@@ -564,6 +569,39 @@ int ensure_staging(dpx_handle h, size_t in_bytes, size_t label_bytes) {
     h->d_labels_bytes = label_bytes;
   }
   return DPX_OK;
+}
+
+// plane records of a batch packed back to back (frame f's records start at the sum of the earlier frames' counts) +
+// the per-frame counts: one block, the frames' offsets by a serial prefix over <= max_batch counts in LDS
+__global__ __launch_bounds__(256) void k_pack_planes(const dpx_frame_stats* __restrict__ stats, const dpx_plane* __restrict__ planes, int pcap,
+                                                     int batch, int32_t* __restrict__ counts, dpx_plane* __restrict__ packed, long long cap,
+                                                     long long* __restrict__ total) {
+  extern __shared__ long long off[];  // batch + 1
+  for (int f = threadIdx.x; f < batch; f += blockDim.x) {
+    const int n = stats[f].segments < pcap ? stats[f].segments : pcap;
+    counts[f] = n;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long o = 0;
+    for (int f = 0; f < batch; ++f) {
+      off[f] = o;
+      o += counts[f];
+    }
+    off[batch] = o;
+    *total = o;
+  }
+  __syncthreads();
+  constexpr int kWords = static_cast<int>(sizeof(dpx_plane) / 4);
+  for (int f = 0; f < batch; ++f) {
+    const long long o = off[f];
+    const int n = counts[f];
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(planes + static_cast<size_t>(f) * pcap);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(packed + o);
+    const long long room = cap - o;
+    const long long words = (room <= 0 ? 0 : (n < room ? n : room)) * kWords;
+    for (long long i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+  }
 }
 
 int host_process(dpx_handle h, const void* in, bool depth, int batch, float fx, float fy, float cx, float cy, int32_t* labels) {
@@ -938,6 +976,91 @@ int dpx_process_pcd_batch(dpx_handle h, const float* xyz, int32_t batch, int32_t
 int dpx_process_depth_batch(dpx_handle h, const uint16_t* depth, int32_t batch, float fx, float fy, float cx, float cy,
                             int32_t* labels) {
   return host_process(h, depth, true, batch, fx, fy, cx, cy, labels);
+}
+
+int dpx_process_depth_batch_cells(dpx_handle h, const uint16_t* depth, int32_t batch, float fx, float fy, float cx, float cy,
+                                  int32_t* cell_labels, int32_t* n_planes, dpx_plane* planes, int64_t planes_cap, int64_t* planes_total) {
+  if (!h) return fail(DPX_ERR_ARG, "null handle");
+  if (batch < 0 || batch > h->max_batch)
+    return fail(DPX_ERR_ARG, "batch " + std::to_string(batch) + " exceeds max_batch " + std::to_string(h->max_batch));
+  if (h->cfg.ransac_refinement) return fail(DPX_ERR_ARG, "cell-level output is not defined with ransac_refinement (it edits single pixels)");
+  if (planes_total) *planes_total = 0;
+  if (batch == 0) return DPX_OK;
+  if (!depth || !cell_labels) return fail(DPX_ERR_ARG, "null buffer");
+  if (planes && planes_cap < 0) return fail(DPX_ERR_ARG, "negative planes_cap");
+  DPX_HIP(hipSetDevice(h->device));
+  const size_t N = static_cast<size_t>(h->H) * h->W, C = static_cast<size_t>(h->prm.C);
+  int rc = ensure_staging(h, N * batch * sizeof(uint16_t), 16);
+  if (rc) return rc;
+  const size_t pack_cap = static_cast<size_t>(h->max_batch) * h->pcap;
+  if (!h->d_pack) {
+    DPX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_pack), pack_cap * sizeof(dpx_plane)));
+    DPX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_pack_counts), static_cast<size_t>(h->max_batch) * sizeof(int32_t) + sizeof(long long)));
+  }
+  DPX_HIP(hipMemcpyAsync(h->d_in, depth, N * batch * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
+  h->no_pixel_labels = true;
+  rc = run_pipeline(h, h->d_in, true, batch, fx, fy, cx, cy, h->d_labels, h->stream);
+  h->no_pixel_labels = false;
+  if (rc) return rc;
+  DPX_HIP(hipMemcpyAsync(cell_labels, h->d_cell_labels, C * batch * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  long long total = 0;
+  if (n_planes || planes || planes_total) {
+    // (the count array is followed by the 8-byte total: max_batch ints are 8-byte aligned only for even max_batch)
+    long long* d_total = reinterpret_cast<long long*>(reinterpret_cast<char*>(h->d_pack_counts) +
+                                                      ((static_cast<size_t>(h->max_batch) * sizeof(int32_t) + 7) & ~size_t(7)));
+    hipLaunchKernelGGL(k_pack_planes, dim3(1), dim3(256), (static_cast<size_t>(batch) + 1) * sizeof(long long), h->stream, h->d_stats,
+                       h->d_planes, h->pcap, batch, h->d_pack_counts, h->d_pack, static_cast<long long>(pack_cap), d_total);
+    DPX_HIP(hipGetLastError());
+    DPX_HIP(hipMemcpyAsync(&total, d_total, sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    if (n_planes) DPX_HIP(hipMemcpyAsync(n_planes, h->d_pack_counts, static_cast<size_t>(batch) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    DPX_HIP(hipStreamSynchronize(h->stream));
+    if (planes_total) *planes_total = total;
+    if (planes) {
+      const long long ncopy = total < planes_cap ? total : planes_cap;
+      if (ncopy > 0) DPX_HIP(hipMemcpy(planes, h->d_pack, static_cast<size_t>(ncopy) * sizeof(dpx_plane), hipMemcpyDeviceToHost));
+      if (total > planes_cap)
+        return fail(DPX_ERR_CAPACITY, "plane buffer holds " + std::to_string(planes_cap) + " records, the batch has " + std::to_string(total));
+    }
+  } else {
+    DPX_HIP(hipStreamSynchronize(h->stream));
+  }
+  return DPX_OK;
+}
+
+int dpx_expand_cell_labels(int32_t image_height, int32_t image_width, int32_t patch_size, const int32_t* cell_labels, int32_t batch,
+                           int32_t* labels) {
+  if (image_height < 0 || image_width < 0 || batch < 0 || patch_size <= 0) return fail(DPX_ERR_ARG, "bad shape");
+  if (batch == 0 || image_height == 0 || image_width == 0) return DPX_OK;
+  if (!cell_labels || !labels) return fail(DPX_ERR_ARG, "null buffer");
+  // grid of plane_extractor.cpp:155-160: nh, nv from the configured patch size, P clamped to the image afterwards
+  const int nh = image_width / patch_size, nv = image_height / patch_size;
+  const int P = std::min(patch_size, std::min(image_height, image_width));
+  for (int32_t f = 0; f < batch; ++f) {
+    const int32_t* cl = cell_labels + static_cast<size_t>(f) * nh * nv;
+    int32_t* out = labels + static_cast<size_t>(f) * image_height * image_width;
+    for (int row = 0; row < image_height; ++row) {
+      const int cr = row / P;
+      int32_t* o = out + static_cast<size_t>(row) * image_width;
+      for (int col = 0; col < image_width; ++col) {
+        const int cc = col / P;
+        o[col] = (cr < nv && cc < nh) ? cl[static_cast<size_t>(cr) * nh + cc] : 0;  // plane_extractor.cpp:464-465 (labels already merged)
+      }
+    }
+  }
+  return DPX_OK;
+}
+
+void* dpx_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {
+    fail(DPX_ERR_HIP, "hipHostMalloc failed");
+    return nullptr;
+  }
+  return p;
+}
+
+void dpx_host_free(void* p) {
+  if (p) hipHostFree(p);
 }
 
 int dpx_process_depth_batch_device(dpx_handle h, const void* d_depth, int32_t batch, float fx, float fy, float cx,

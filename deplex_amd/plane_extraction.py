@@ -104,8 +104,7 @@ class PlaneExtractor:
         return labels[:n]
 
     # ---- batched / fused entry points ----------------------------------------------------------------
-    def process_depth_batch(self, depth, fx, fy, cx, cy) -> np.ndarray:
-        """depth: (B, H, W) uint16 -> labels (B, H*W) int32; back-projection fused on the device."""
+    def _check_depth(self, depth):
         depth = np.ascontiguousarray(depth, dtype=np.uint16)
         if depth.ndim == 2:
             depth = depth[None]
@@ -113,10 +112,56 @@ class PlaneExtractor:
         if (h, w) != (self.image_height, self.image_width):
             raise DeplexError(_capi.DPX_ERR_SHAPE, f"Error! Number of points doesn't match image shape: {h * w} != "
                               f"{self.image_height} x {self.image_width}")
-        labels = np.empty((b, h * w), dtype=np.int32)
-        _capi.check(_capi.lib().dpx_process_depth_batch(self._h, depth.ctypes.data, b, fx, fy, cx, cy,
-                                                       labels.ctypes.data))
-        return labels
+        return depth
+
+    def process_depth_batch(self, depth, fx, fy, cx, cy, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """depth: (B, H, W) uint16 -> labels (B, H*W) int32; back-projection fused on the device.  `out`: a C-contiguous
+        int32 array of that shape to write into (e.g. a slice of a page-locked buffer, deplex_amd.pinned_empty)."""
+        depth = self._check_depth(depth)
+        b, h, w = depth.shape
+        if out is None:
+            out = np.empty((b, h * w), dtype=np.int32)
+        elif out.dtype != np.int32 or out.size != b * h * w or not out.flags.c_contiguous:
+            raise TypeError("out must be a C-contiguous int32 array of B * H * W elements")
+        _capi.check(_capi.lib().dpx_process_depth_batch(self._h, depth.ctypes.data, b, fx, fy, cx, cy, out.ctypes.data))
+        return out.reshape(b, h * w)
+
+    def process_depth_batch_cells(self, depth, fx, fy, cx, cy, out: Optional[np.ndarray] = None, planes: bool = True):
+        """Cell-level output of the same computation (dpx_process_depth_batch_cells): (cell_labels (B, nv, nh) int32 —
+        the merged 1-based label of every cell, what the pixel map holds for all pixels of that cell — and, with
+        planes=True, a list of B plane-record arrays).  80x fewer bytes come back over PCIe than with the pixel map."""
+        depth = self._check_depth(depth)
+        b = depth.shape[0]
+        if out is None:
+            out = np.empty((b, self.nv, self.nh), dtype=np.int32)
+        elif out.dtype != np.int32 or out.size != b * self.nv * self.nh or not out.flags.c_contiguous:
+            raise TypeError("out must be a C-contiguous int32 array of B * nv * nh elements")
+        if not planes:
+            _capi.check(_capi.lib().dpx_process_depth_batch_cells(self._h, depth.ctypes.data, b, fx, fy, cx, cy, out.ctypes.data,
+                                                                 None, None, 0, None))
+            return out.reshape(b, self.nv, self.nh), None
+        counts = np.zeros(max(b, 1), dtype=np.int32)
+        cap = max(64 * b, 1)
+        total = C.c_int64()
+        while True:
+            recs = np.zeros(cap, dtype=_capi.PLANE_DTYPE)
+            rc = _capi.lib().dpx_process_depth_batch_cells(self._h, depth.ctypes.data, b, fx, fy, cx, cy, out.ctypes.data,
+                                                          counts.ctypes.data, recs.ctypes.data, cap, C.byref(total))
+            if rc == _capi.DPX_ERR_CAPACITY and total.value > cap:  # (rare: more than 64 planes per frame on average)
+                cap = int(total.value)
+                continue
+            _capi.check(rc)
+            break
+        offs = np.concatenate([[0], np.cumsum(counts[:b])])
+        return out.reshape(b, self.nv, self.nh), [recs[offs[k]:offs[k + 1]] for k in range(b)]
+
+    def expand_cell_labels(self, cell_labels) -> np.ndarray:
+        """Impl::toImageLabels (plane_extractor.cpp:455-470) on the host: (B, nv, nh) cell labels -> (B, H*W) pixel labels."""
+        cl = np.ascontiguousarray(cell_labels, dtype=np.int32).reshape(-1, self.nv, self.nh)
+        out = np.empty((cl.shape[0], self.image_height * self.image_width), dtype=np.int32)
+        _capi.check(_capi.lib().dpx_expand_cell_labels(self.image_height, self.image_width, int(self.config.patch_size),
+                                                      cl.ctypes.data, cl.shape[0], out.ctypes.data))
+        return out
 
     def process_pcd_batch(self, pcd) -> np.ndarray:
         pcd = np.ascontiguousarray(pcd, dtype=np.float32)

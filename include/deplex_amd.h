@@ -11,6 +11,7 @@
  */
 #ifndef DEPLEX_AMD_H
 #define DEPLEX_AMD_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -125,6 +126,30 @@ int dpx_process_pcd_batch(dpx_handle h, const float* xyz, int32_t batch, int32_t
  * labels: batch x H x W int32 (HOST). */
 int dpx_process_depth_batch(dpx_handle h, const uint16_t* depth, int32_t batch, float fx, float fy, float cx,
                             float cy, int32_t* labels);
+
+/* The same call with CELL-LEVEL output: what PlaneExtractor::process() knows before toImageLabels
+ * (plane_extractor.cpp:455-470) blows it up to one int32 per pixel.  cell_labels: batch x nv x nh int32 (HOST), the
+ * merged 1-based label of every cell (0 = none) — exactly what the pixel map holds for all pixels of the cell;
+ * n_planes (batch int32, may be NULL) and planes (HOST, may be NULL): the frames' plane records packed back to
+ * back, frame f's first record at the sum of n_planes[0..f); planes_cap = records the buffer can hold; *planes_total
+ * (may be NULL) receives the number of records of the batch.  DPX_ERR_CAPACITY (records up to planes_cap copied) if
+ * the buffer is too small.  Device-to-host traffic per 640x480 frame: 12 KB + ~3 KB instead of 1.2 MB — the
+ * host-pointer entry points are PCIe-bound, so this is ~3x the end-to-end frame rate.
+ * Not defined with ransac_refinement (which edits single pixels): DPX_ERR_ARG. */
+int dpx_process_depth_batch_cells(dpx_handle h, const uint16_t* depth, int32_t batch, float fx, float fy, float cx,
+                                  float cy, int32_t* cell_labels, int32_t* n_planes, dpx_plane* planes,
+                                  int64_t planes_cap, int64_t* planes_total);
+/* Impl::toImageLabels (plane_extractor.cpp:455-470) on the host, for callers of the cell-level form that want a pixel
+ * map after all: labels[f][row][col] = cell_labels[f][row / P][col / P] (0 outside the nv*P x nh*P grid; P = the
+ * stored patch size min(patch_size, H, W), nh = W / patch_size, nv = H / patch_size).  Plain C loop, no device. */
+int dpx_expand_cell_labels(int32_t image_height, int32_t image_width, int32_t patch_size, const int32_t* cell_labels,
+                           int32_t batch, int32_t* labels);
+
+/* Page-locked host memory for the host-pointer entry points (hipHostMalloc): copies from / to such buffers go
+ * straight over PCIe instead of through the runtime's staging buffer, and one buffer can be the target of several
+ * devices' copies at once (disjoint slices: deplex_amd.ShardedExtractor).  NULL on failure. */
+void* dpx_host_alloc(size_t bytes);
+void dpx_host_free(void* p);
 
 /* Device-pointer, stream-ordered forms (no copies, no synchronisation): d_* are device pointers on the
  * handle's device, hip_stream is a hipStream_t (NULL = default stream).  Used by pipelines and bench.py. */

@@ -648,6 +648,74 @@ def test_host_batches_with_records(D, oracle):
     full_compare(D, oracle, synth.synth_batch(8, 120, 160, seed0=5), synth.intrinsics_for(120, 160), cfg)
 
 
+def test_cell_level_output_matches_pixel_labels(D, oracle):
+    """dpx_process_depth_batch_cells: the cell labels expanded on the host (dpx_expand_cell_labels =
+    plane_extractor.cpp:455-470) equal the pixel map of dpx_process_depth_batch and the oracle's; the packed plane
+    records equal the per-frame getters'; capacity and refinement errors."""
+    import ctypes as C
+    from deplex_amd import _capi
+    K = synth.read_K(synth.TUM_K)
+    cases = [(synth.tum_stream(5), tuple(float(v) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2])), {}),
+             (synth.synth_batch(3, 245, 333, seed0=40), synth.intrinsics_for(245, 333), {"patch_size": 7}),   # ragged image
+             (synth.synth_batch(2, 960, 1280, seed0=6), synth.intrinsics_for(960, 1280), {})]               # hundreds of planes
+    oracle.set_math("devmath")
+    for depth, intr, ov in cases:
+        b, h, w = depth.shape
+        ocfg = oracle.default_config(**ov)
+        ex = D.PlaneExtractor(h, w, to_cfg(D, ocfg), max_batch=b)
+        cl, planes = ex.process_depth_batch_cells(depth, *intr)
+        assert cl.shape == (b, ex.nv, ex.nh) and cl.dtype == np.int32
+        ref = np.stack([oracle.process(ocfg, h, w, oracle.backproject(d, *intr)) for d in depth])
+        assert np.array_equal(ex.expand_cell_labels(cl), ref)
+        for k in range(b):
+            assert np.array_equal(cl[k], ex.cell_labels(k))
+            assert_planes_equal(planes[k], ex.planes(k))
+        pix = ex.process_depth_batch(depth, *intr)
+        assert np.array_equal(pix, ref)
+        cl2, none = ex.process_depth_batch_cells(depth, *intr, planes=False)
+        assert none is None and np.array_equal(cl2, cl)
+        # too small a plane buffer: DPX_ERR_CAPACITY, the total reported, the records that fit copied
+        total_planes = sum(len(p) for p in planes)
+        if total_planes > 1:
+            recs = np.zeros(1, dtype=_capi.PLANE_DTYPE)
+            counts = np.zeros(b, dtype=np.int32)
+            tot = C.c_int64()
+            out = np.empty((b, ex.nv, ex.nh), dtype=np.int32)
+            rc = _capi.lib().dpx_process_depth_batch_cells(ex._h, depth.ctypes.data, b, *intr, out.ctypes.data, counts.ctypes.data,
+                                                          recs.ctypes.data, 1, C.byref(tot))
+            assert rc == _capi.DPX_ERR_CAPACITY and tot.value == total_planes and list(counts) == [len(p) for p in planes]
+            first = next(p for p in planes if len(p))
+            assert_planes_equal(recs, first[:1])
+    cfg = D.Config()
+    cfg.ransac_refinement = True
+    with pytest.raises(D.DeplexError) as ei:
+        D.PlaneExtractor(240, 320, cfg).process_depth_batch_cells(synth.synth_batch(1, 240, 320), *synth.intrinsics_for(240, 320))
+    assert ei.value.code == _capi.DPX_ERR_ARG
+
+
+def test_sharded_extractor_two_shards_on_one_gpu(D, oracle):
+    """deplex_amd.ShardedExtractor with devices=[0, 0] (two extractors, two host threads, one GPU): ragged shards, chunks
+    of max_batch, results in disjoint slices of one page-locked buffer — label maps and cell-level output vs the oracle."""
+    depth = synth.synth_batch(21, 240, 320, seed0=300)
+    intr = synth.intrinsics_for(240, 320)
+    oracle.set_math("devmath")
+    ref = oracle.process_depth_batch(oracle.default_config(), depth, *intr, threads=min(8, os.cpu_count() or 1))
+    sh = D.ShardedExtractor(240, 320, D.Config(), devices=[0, 0], max_batch=4)
+    assert sh.shards(21) == [(0, 10), (10, 21)]
+    out = D.pinned_empty((21, 240 * 320), np.int32)
+    out[:] = -1
+    got = sh.process_depth_batch(depth, *intr, out=out)
+    assert got.base is not None and np.array_equal(out, ref)
+    assert np.array_equal(sh.process_depth_batch(depth[:1], *intr), ref[:1])  # fewer frames than devices
+    cl, planes = sh.process_depth_batch_cells(depth, *intr)
+    assert np.array_equal(sh.extractors[0].expand_cell_labels(cl), ref)
+    single = D.PlaneExtractor(240, 320, max_batch=21)
+    single.process_depth_batch(depth, *intr)
+    for k in (0, 9, 10, 20):
+        assert_planes_equal(planes[k], single.planes(k))
+    sh.close()
+
+
 def test_instances_are_independent_across_host_threads(D, oracle):
     """SURVEY 8(b) threading contract: an instance is not re-entrant, distinct instances are independent.  Four host
     threads, one extractor each, different frames, concurrent calls (ctypes releases the GIL)."""

@@ -1,34 +1,45 @@
-"""PCIe-inclusive rate of the host-pointer entry point dpx_process_depth_batch (H2D depth + kernels + D2H labels),
-pageable vs pinned host buffers, next to the device-resident rate."""
-import os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+"""End-to-end rate of the host-pointer entry points (depth frames in host memory -> results in host memory), PCIe
+included: the pixel-label form (dpx_process_depth_batch, 0.6 MB in + 1.2 MB out per 640x480 frame), the cell-level form
+(dpx_process_depth_batch_cells, 0.6 MB in + ~15 KB out) and the sharded entry point with two extractors on the one GPU.
+usage: host_api_rate.py [batch]"""
+import sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
-import numpy as np, torch
+import numpy as np
 import deplex_amd as D, synth
-from deplex_amd import _capi
 
-B = 64
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 depth = synth.tum_stream(B)
 K = synth.read_K(synth.TUM_K)
 intr = tuple(float(v) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2]))
+N = 480 * 640
+
+
+def rate(fn, reps=12):
+    fn(); fn()
+    best = 1e9
+    for _ in range(reps):
+        t0 = time.perf_counter(); fn(); best = min(best, time.perf_counter() - t0)
+    return best
+
+
 ex = D.PlaneExtractor(480, 640, max_batch=B)
-L = _capi.lib()
-def run(name, d_host, l_host, n=20):
-    for _ in range(3):
-        _capi.check(L.dpx_process_depth_batch(ex._h, d_host.ctypes.data if hasattr(d_host, "ctypes") else d_host.data_ptr(), B, *intr,
-                                              l_host.ctypes.data if hasattr(l_host, "ctypes") else l_host.data_ptr()))
-    t0 = time.perf_counter()
-    for _ in range(n):
-        _capi.check(L.dpx_process_depth_batch(ex._h, d_host.ctypes.data if hasattr(d_host, "ctypes") else d_host.data_ptr(), B, *intr,
-                                              l_host.ctypes.data if hasattr(l_host, "ctypes") else l_host.data_ptr()))
-    dt = (time.perf_counter() - t0) / n
-    by = B * 480 * 640 * 6
-    print(f"{name}: {dt*1e3:.2f} ms per batch of {B} -> {B/dt:.0f} fps, {by/dt/1e9:.1f} GB/s over PCIe (2 B in + 4 B out per pixel)")
-labels = np.empty((B, 480 * 640), dtype=np.int32)
-run("pageable host buffers", depth, labels)
-dp = torch.from_numpy(depth.view(np.int16)).pin_memory()
-lp = torch.empty((B, 480 * 640), dtype=torch.int32).pin_memory()
-run("pinned host buffers", dp, lp)
-assert np.array_equal(lp.numpy(), labels)
+pin_in = D.pinned_empty(depth.shape, np.uint16); pin_in[:] = depth
+pin_out = D.pinned_empty((B, N), np.int32)
+pin_cl = D.pinned_empty((B, ex.nv, ex.nh), np.int32)
+pag_out = np.empty((B, N), np.int32)
+for name, fn, out_bytes in (
+        ("pixel labels, pageable buffers", lambda: ex.process_depth_batch(depth, *intr, out=pag_out), 4 * N),
+        ("pixel labels, page-locked buffers", lambda: ex.process_depth_batch(pin_in, *intr, out=pin_out), 4 * N),
+        ("cell labels + planes, pageable in", lambda: ex.process_depth_batch_cells(depth, *intr, out=pin_cl), 4 * ex.nv * ex.nh),
+        ("cell labels + planes, page-locked in", lambda: ex.process_depth_batch_cells(pin_in, *intr, out=pin_cl), 4 * ex.nv * ex.nh),
+        ("cell labels only, page-locked in", lambda: ex.process_depth_batch_cells(pin_in, *intr, out=pin_cl, planes=False), 4 * ex.nv * ex.nh)):
+    dt = rate(fn)
+    print(f"{name:40s}: {dt * 1e3:6.2f} ms per {B} frames = {B / dt:8.0f} frames/s; H2D {B * 2 * N / dt / 1e9:5.1f} GB/s, "
+          f"D2H {B * out_bytes / dt / 1e9:5.2f} GB/s", flush=True)
+sh = D.ShardedExtractor(480, 640, devices=[0, 0], max_batch=B // 2)
+dt = rate(lambda: sh.process_depth_batch(pin_in, *intr, out=pin_out))
+print(f"{'sharded [0, 0], pixel labels, pinned':40s}: {dt * 1e3:6.2f} ms = {B / dt:8.0f} frames/s", flush=True)
+dt = rate(lambda: sh.process_depth_batch_cells(pin_in, *intr))
+print(f"{'sharded [0, 0], cell labels + planes':40s}: {dt * 1e3:6.2f} ms = {B / dt:8.0f} frames/s", flush=True)
