@@ -131,6 +131,9 @@ def main():
     ap.add_argument("--input", choices=("depth", "cloud"), default="depth",
                     help="depth: u16 frames, back-projection fused (the metric); cloud: organised float32 clouds, the reference API's input form")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the long-run-shape measurement that follows a short timed region")
+    ap.add_argument("--sustained-steps", type=int, default=2000)
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-to-host (PCIe-inclusive) measurement")
     ap.add_argument("--parity-frames", type=int, default=4)
     ap.add_argument("--inputs", type=int, default=8,
                     help="distinct input batches the steps rotate over (8 x 39 MB of depth frames exceed the 256 MB Infinity Cache)")
@@ -270,29 +273,122 @@ def main():
     if rank == 0 and not args.no_cloud_roofline:
         cloud_ms, cloud_bytes = planefit_series(True, max(4, args.roofline_iters // 4))
 
-    # parity spot check against the oracle (outside the timed region; the oracle is only the checker)
+    # parity spot check against the oracle (outside the timed region; the oracle is only the checker).  EVERY rank checks
+    # its own frames and buffers; the verdicts are MIN-reduced and a single failing rank makes rank 0 refuse to report.
     parity = "unchecked"
-    if rank == 0 and args.parity_frames > 0:
-        from oracle import oracle as O
-        O.set_math("devmath")
-        nchk = min(args.parity_frames, B)
-        last = args.steps - 1
-        # the last step and the first inputs of the rotation (output buffer k holds the result of input k % R)
-        nbuf = min(max(args.steps, args.warmup), S * G)  # (warm-up and timed steps both index the buffers from 0)
-        check = [last % (S * G)] + [k for k in range(min(R, nbuf)) if k != last % (S * G)][:2]
-        ncheck = 0
-        for k in check:
-            got = d_labels[k, :nchk].cpu().numpy()
-            ref = O.process_depth_batch(O.default_config(), depths[k % R][:nchk], *intr, threads=min(nchk, os.cpu_count() or 1))
-            if not np.array_equal(got, ref):
-                raise SystemExit("bench: HIP label maps differ from the oracle — refusing to report a number")
-            ncheck += nchk
-        # all output buffers of the in-flight window that hold the same input must hold the same bits (catches a slot
-        # being reused before its previous submission finished)
-        same = all(bool(torch.equal(d_labels[k], d_labels[k % R])) for k in range(R, nbuf))
-        if not same:
-            raise SystemExit("bench: output buffers of different in-flight submissions differ — refusing to report a number")
-        parity = f"bit-exact label maps vs oracle on {ncheck} frames; {nbuf} in-flight output buffers consistent over {R} rotating inputs"
+    parity_ok, parity_err = 1, ""
+    if args.parity_frames > 0:
+        try:
+            from oracle import oracle as O
+            O.set_math("devmath")
+            nchk = min(args.parity_frames, B)
+            last = args.steps - 1
+            # the last step and the first inputs of the rotation (output buffer k holds the result of input k % R)
+            nbuf = min(max(args.steps, args.warmup), S * G)  # (warm-up and timed steps both index the buffers from 0)
+            check = [last % (S * G)] + [k for k in range(min(R, nbuf)) if k != last % (S * G)][:2]
+            ncheck = 0
+            for k in check:
+                got = d_labels[k, :nchk].cpu().numpy()
+                ref = O.process_depth_batch(O.default_config(), depths[k % R][:nchk], *intr, threads=min(nchk, os.cpu_count() or 1))
+                if not np.array_equal(got, ref):
+                    raise RuntimeError(f"rank {rank}: HIP label maps differ from the oracle (output buffer {k})")
+                ncheck += nchk
+            # all output buffers of the in-flight window that hold the same input must hold the same bits (catches a slot
+            # being reused before its previous submission finished)
+            if not all(bool(torch.equal(d_labels[k], d_labels[k % R])) for k in range(R, nbuf)):
+                raise RuntimeError(f"rank {rank}: output buffers of different in-flight submissions differ")
+            if os.environ.get("DPX_BENCH_FAIL_RANK") == str(rank):  # test hook (tests/test_gpu_parity.py): a rank that fails
+                raise RuntimeError(f"rank {rank}: injected parity failure")
+            parity = (f"bit-exact label maps vs oracle on {ncheck} frames per rank; {nbuf} in-flight output buffers consistent over "
+                      f"{R} rotating inputs; checked on all {world} rank(s)")
+        except Exception as e:  # noqa: BLE001  (the verdict must reach the reduction below on every rank)
+            parity_ok, parity_err = 0, str(e)
+        if world > 1:
+            t = torch.tensor([parity_ok], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            all_ok = int(t.item())
+        else:
+            all_ok = parity_ok
+        if not all_ok:
+            if parity_err:
+                print(f"bench: {parity_err}", file=sys.stderr, flush=True)
+            raise SystemExit("bench: parity check failed on at least one rank — refusing to report a number")
+
+    # ---- the long-run pipeline shape in the same record.  The driver times 20 steps (4 whole groups of 5 on 16 slots); the
+    # shape that sustains the highest rate keeps 4 slots x groups of 8 in flight and needs a few hundred steps to get
+    # there.  Same workload, same buffers-in-HBM rule, same barrier + synchronise bracket, MAX over ranks.
+    sustained = None
+    if args.workload == "tum_stream" and args.input == "depth" and not args.no_sustained:
+        if long_run and not big:
+            sus_elapsed, sus_steps, sus_S, sus_G = elapsed, args.steps, S, G
+        else:
+            sus_S, sus_G, sus_steps = 4, 8, args.sustained_steps
+            del pipe
+            pipe2 = D.Pipeline(H, W, D.Config(), batch=B, slots=sus_S, group=sus_G, device=local_rank)
+            for k in range(sus_S):
+                pipe2.slot(k).prepare_intrinsics(*intr)
+            NB2 = sus_S * sus_G
+            d_labels2 = d_labels if NB2 <= NB else torch.empty((NB2, B, N), dtype=torch.int32, device=dev)
+            outs2 = [d_labels2[k].data_ptr() for k in range(NB2)]
+
+            def step2(i):
+                pipe2.submit_depth(in_ptrs[i % R], B, *intr, outs2[i % NB2])
+
+            def sync2():
+                pipe2.sync()
+                torch.cuda.synchronize(dev)
+
+            sus_elapsed = timed_region(step2, sync2, barrier, sus_steps, 256)
+            if world > 1:
+                t = torch.tensor([sus_elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                sus_elapsed = float(t.item())
+            exs = [pipe2.slot(k) for k in range(sus_S)]  # (the plane-fit series below runs on a live handle)
+            pipe = pipe2
+        sus_fps = B * sus_steps * world / sus_elapsed
+        sus_gbs = sus_fps / world * N * 6 / 1e9
+        sustained = {"value": round(sus_fps, 1), "unit": "frames/s", "steps": sus_steps, "warmup": 256,
+                     "ms_per_step": round(sus_elapsed / sus_steps * 1e3, 4), "groups_in_flight": sus_S, "batches_per_launch": sus_G,
+                     "pipeline_roofline": {"bound": "hbm", "achieved": round(sus_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": round(sus_gbs / HBM_PEAK_GBS, 4)},
+                     "note": "same workload and rules as `value`, run right after the timed region with the long-run pipeline shape"}
+
+    # ---- end to end: depth frames in page-locked HOST memory -> results in HOST memory, PCIe included (what a caller of the
+    # reference API sees: examples/process_sequence.cpp:30-53).  Never `value`.  Rank 0 at N = 1 only (the ranks of a node
+    # share the host's PCIe root and memory bandwidth; a per-rank figure measured one at a time would not add up).
+    end_to_end = None
+    if world == 1 and not args.no_end_to_end and args.input == "depth":
+        exh = D.PlaneExtractor(H, W, D.Config(), max_batch=B, device=local_rank)
+        pin_in = D.pinned_empty(depth.shape, np.uint16)
+        pin_in[:] = depth
+        pin_out = D.pinned_empty((B, N), np.int32)
+        pin_cl = D.pinned_empty((B, exh.nv, exh.nh), np.int32)
+
+        def rate(fn, reps):
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            return (time.perf_counter() - t0) / reps
+
+        reps = max(3, min(30, int(2e9 / (B * N * 6))))
+        t_pix = rate(lambda: exh.process_depth_batch(pin_in, *intr, out=pin_out), reps)
+        t_cel = rate(lambda: exh.process_depth_batch_cells(pin_in, *intr, out=pin_cl), reps)
+        ok_e2e = np.array_equal(pin_out, np.asarray(exh.expand_cell_labels(pin_cl)))
+        if not ok_e2e:
+            raise SystemExit("bench: cell-level output expanded on the host differs from the pixel label map")
+        end_to_end = {
+            "pixel_labels": {"value": round(B / t_pix, 1), "unit": "frames/s", "ms_per_batch": round(t_pix * 1e3, 3),
+                             "h2d_GBps": round(B * N * 2 / t_pix / 1e9, 2), "d2h_GBps": round(B * N * 4 / t_pix / 1e9, 2),
+                             "entry": "dpx_process_depth_batch (2 B in + 4 B out per pixel)"},
+            "cell_labels": {"value": round(B / t_cel, 1), "unit": "frames/s", "ms_per_batch": round(t_cel * 1e3, 3),
+                            "h2d_GBps": round(B * N * 2 / t_cel / 1e9, 2),
+                            "d2h_GBps": round(B * exh.nv * exh.nh * 4 / t_cel / 1e9, 3),
+                            "entry": "dpx_process_depth_batch_cells (cell labels + plane records; expanded on the host they equal the pixel map: checked)"},
+            "host_buffers": "page-locked (dpx_host_alloc)", "batch": B,
+            "note": "one call at a time on one stream; host-to-device and device-to-host copies do not overlap on this platform "
+                    "(tools/duplex_probe.py: 53 GB/s either way alone, 26.6 GB/s each when both run)"}
+        del exh
 
     if rank == 0:
         total_frames = B * args.steps * world
@@ -324,6 +420,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl_desc, "patch_size": 10, "batch_per_gpu": B, "groups_in_flight": S, "batches_per_launch": G,
+                       "shape_auto_selected": args.streams <= 0 and args.group <= 0,
                        "distinct_input_batches": R, "input_bytes_in_rotation": int(R * B * N * (12 if args.input == "cloud" else 2)),
                        "streams": f"{S} (one per group in flight), GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}",
                        "arithmetic": "f32 moments (reference order), f64 3x3 eigen, int32 labels",
@@ -357,6 +454,10 @@ def main():
                                            "bound": "hbm", "achieved": round(cloud_bytes / (cloud_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": round(cloud_bytes / (cloud_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                            "traffic": cloud_traffic, "bytes_per_launch": cloud_bytes, "avg_launch_ms": round(cloud_ms, 4)}
+        if sustained:
+            out["sustained"] = sustained
+        if end_to_end:
+            out["end_to_end"] = end_to_end
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(depth, intr, min(16, os.cpu_count() or 1))  # the box's CPU share for one GPU
         print(json.dumps(out), flush=True)

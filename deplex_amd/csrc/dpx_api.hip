@@ -84,8 +84,7 @@ struct dpx_handle_s {
   unsigned long long* d_sort_keys = nullptr;  // [B][Cpad]
   uint32_t* d_bin_off = nullptr;              // [B][nb + 1]
   uint32_t* d_gqpos = nullptr;                // tier 0: [B][C]
-  dpx_plane* d_pack = nullptr;                // cell-level output: the batch's plane records packed back to back
-  int32_t* d_pack_counts = nullptr;           // [max_batch] counts + 8-byte total
+  char* h_cells_stage = nullptr;              // cell-level output: page-locked staging the device writes into
   uint8_t* d_gflags = nullptr;
   uint8_t* d_gowner = nullptr;
   uint32_t* d_gqueue = nullptr;
@@ -126,8 +125,7 @@ void free_all(dpx_handle h) {
   hipFree(h->d_meta);
   hipFree(h->d_order);
   hipFree(h->d_grow_start);
-  if (h->d_pack) hipFree(h->d_pack);
-  if (h->d_pack_counts) hipFree(h->d_pack_counts);
+  if (h->h_cells_stage) hipHostFree(h->h_cells_stage);
   hipFree(h->d_cand);
   hipFree(h->d_planes);
   hipFree(h->d_cell_labels);
@@ -571,36 +569,49 @@ int ensure_staging(dpx_handle h, size_t in_bytes, size_t label_bytes) {
   return DPX_OK;
 }
 
-// plane records of a batch packed back to back (frame f's records start at the sum of the earlier frames' counts) +
-// the per-frame counts: one block, the frames' offsets by a serial prefix over <= max_batch counts in LDS
-__global__ __launch_bounds__(256) void k_pack_planes(const dpx_frame_stats* __restrict__ stats, const dpx_plane* __restrict__ planes, int pcap,
-                                                     int batch, int32_t* __restrict__ counts, dpx_plane* __restrict__ packed, long long cap,
-                                                     long long* __restrict__ total) {
+// Cell-level output of a batch, written by the device straight into a page-locked host buffer (zero-copy stores over
+// PCIe, 16 bytes per lane): the merged cell labels, the per-frame plane counts, their total, and the plane records packed
+// back to back (frame f's records start at the sum of the earlier frames' counts).  A device-to-host hipMemcpy of a few
+// hundred KB costs a fixed ~0.37 ms on this platform (tools/duplex_probe.py), more than everything else in the call.
+// Block 0 also does the serial prefix over <= max_batch counts; every block then copies its share.
+__global__ __launch_bounds__(256) void k_pack_out(const dpx_frame_stats* __restrict__ stats, const dpx_plane* __restrict__ planes, int pcap, int batch,
+                                                  const int32_t* __restrict__ cell_labels, long long n_cell_words, int32_t* __restrict__ out_cells,
+                                                  int32_t* __restrict__ out_counts, long long* __restrict__ out_total, dpx_plane* __restrict__ out_planes,
+                                                  long long cap) {
   extern __shared__ long long off[];  // batch + 1
-  for (int f = threadIdx.x; f < batch; f += blockDim.x) {
-    const int n = stats[f].segments < pcap ? stats[f].segments : pcap;
-    counts[f] = n;
-  }
+  for (int f = threadIdx.x; f < batch; f += blockDim.x) off[f + 1] = stats[f].segments < pcap ? stats[f].segments : pcap;
   __syncthreads();
   if (threadIdx.x == 0) {
     long long o = 0;
     for (int f = 0; f < batch; ++f) {
+      const long long n = off[f + 1];
       off[f] = o;
-      o += counts[f];
+      o += n;
     }
     off[batch] = o;
-    *total = o;
   }
   __syncthreads();
-  constexpr int kWords = static_cast<int>(sizeof(dpx_plane) / 4);
-  for (int f = 0; f < batch; ++f) {
-    const long long o = off[f];
-    const int n = counts[f];
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(planes + static_cast<size_t>(f) * pcap);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(packed + o);
-    const long long room = cap - o;
-    const long long words = (room <= 0 ? 0 : (n < room ? n : room)) * kWords;
-    for (long long i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+  if (blockIdx.x == 0) {
+    for (int f = threadIdx.x; f < batch; f += blockDim.x) out_counts[f] = static_cast<int32_t>(off[f + 1] - off[f]);
+    if (threadIdx.x == 0) *out_total = off[batch];
+  }
+  const long long tid = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x, nthr = static_cast<long long>(gridDim.x) * blockDim.x;
+  {  // cell labels: int4 where the word count allows (device and host buffers are 16-byte aligned)
+    const long long n4 = n_cell_words >> 2;
+    const int4* s4 = reinterpret_cast<const int4*>(cell_labels);
+    int4* d4 = reinterpret_cast<int4*>(out_cells);
+    for (long long i = tid; i < n4; i += nthr) d4[i] = s4[i];
+    for (long long i = (n4 << 2) + tid; i < n_cell_words; i += nthr) out_cells[i] = cell_labels[i];
+  }
+  if (out_planes) {
+    constexpr int kWords = static_cast<int>(sizeof(dpx_plane) / 4);
+    for (int f = 0; f < batch; ++f) {
+      const long long o = off[f], n = off[f + 1] - o, room = cap - o;
+      const long long words = (room <= 0 ? 0 : (n < room ? n : room)) * kWords;
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(planes + static_cast<size_t>(f) * pcap);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(out_planes + o);
+      for (long long i = tid; i < words; i += nthr) dst[i] = src[i];
+    }
   }
 }
 
@@ -992,37 +1003,39 @@ int dpx_process_depth_batch_cells(dpx_handle h, const uint16_t* depth, int32_t b
   const size_t N = static_cast<size_t>(h->H) * h->W, C = static_cast<size_t>(h->prm.C);
   int rc = ensure_staging(h, N * batch * sizeof(uint16_t), 16);
   if (rc) return rc;
-  const size_t pack_cap = static_cast<size_t>(h->max_batch) * h->pcap;
-  if (!h->d_pack) {
-    DPX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_pack), pack_cap * sizeof(dpx_plane)));
-    DPX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_pack_counts), static_cast<size_t>(h->max_batch) * sizeof(int32_t) + sizeof(long long)));
+  // page-locked staging, allocated at the first cell-level call: [cell labels][counts][total][packed plane records]
+  const size_t B = static_cast<size_t>(h->max_batch);
+  const size_t off_counts = (B * C * sizeof(int32_t) + 15) & ~size_t(15);
+  const size_t off_total = off_counts + ((B * sizeof(int32_t) + 15) & ~size_t(15));
+  const size_t off_planes = off_total + 16;
+  const size_t pack_cap = B * static_cast<size_t>(h->pcap);
+  if (!h->h_cells_stage) {
+    DPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_cells_stage), off_planes + pack_cap * sizeof(dpx_plane), hipHostMallocDefault));
   }
+  char* st = h->h_cells_stage;
+  const bool want_planes = planes != nullptr;
   DPX_HIP(hipMemcpyAsync(h->d_in, depth, N * batch * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
   h->no_pixel_labels = true;
   rc = run_pipeline(h, h->d_in, true, batch, fx, fy, cx, cy, h->d_labels, h->stream);
   h->no_pixel_labels = false;
   if (rc) return rc;
-  DPX_HIP(hipMemcpyAsync(cell_labels, h->d_cell_labels, C * batch * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-  long long total = 0;
-  if (n_planes || planes || planes_total) {
-    // (the count array is followed by the 8-byte total: max_batch ints are 8-byte aligned only for even max_batch)
-    long long* d_total = reinterpret_cast<long long*>(reinterpret_cast<char*>(h->d_pack_counts) +
-                                                      ((static_cast<size_t>(h->max_batch) * sizeof(int32_t) + 7) & ~size_t(7)));
-    hipLaunchKernelGGL(k_pack_planes, dim3(1), dim3(256), (static_cast<size_t>(batch) + 1) * sizeof(long long), h->stream, h->d_stats,
-                       h->d_planes, h->pcap, batch, h->d_pack_counts, h->d_pack, static_cast<long long>(pack_cap), d_total);
-    DPX_HIP(hipGetLastError());
-    DPX_HIP(hipMemcpyAsync(&total, d_total, sizeof(long long), hipMemcpyDeviceToHost, h->stream));
-    if (n_planes) DPX_HIP(hipMemcpyAsync(n_planes, h->d_pack_counts, static_cast<size_t>(batch) * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-    DPX_HIP(hipStreamSynchronize(h->stream));
-    if (planes_total) *planes_total = total;
-    if (planes) {
-      const long long ncopy = total < planes_cap ? total : planes_cap;
-      if (ncopy > 0) DPX_HIP(hipMemcpy(planes, h->d_pack, static_cast<size_t>(ncopy) * sizeof(dpx_plane), hipMemcpyDeviceToHost));
-      if (total > planes_cap)
-        return fail(DPX_ERR_CAPACITY, "plane buffer holds " + std::to_string(planes_cap) + " records, the batch has " + std::to_string(total));
-    }
-  } else {
-    DPX_HIP(hipStreamSynchronize(h->stream));
+  const long long words = static_cast<long long>(C) * batch;
+  const unsigned blocks = static_cast<unsigned>(std::max<long long>(1, std::min<long long>(256, (words / 4 + 255) / 256)));
+  hipLaunchKernelGGL(k_pack_out, dim3(blocks), dim3(256), (static_cast<size_t>(batch) + 1) * sizeof(long long), h->stream, h->d_stats, h->d_planes,
+                     h->pcap, batch, h->d_cell_labels, words, reinterpret_cast<int32_t*>(st), reinterpret_cast<int32_t*>(st + off_counts),
+                     reinterpret_cast<long long*>(st + off_total), want_planes ? reinterpret_cast<dpx_plane*>(st + off_planes) : nullptr,
+                     static_cast<long long>(pack_cap));
+  DPX_HIP(hipGetLastError());
+  DPX_HIP(hipStreamSynchronize(h->stream));
+  std::memcpy(cell_labels, st, static_cast<size_t>(words) * sizeof(int32_t));
+  const long long total = *reinterpret_cast<const long long*>(st + off_total);
+  if (n_planes) std::memcpy(n_planes, st + off_counts, static_cast<size_t>(batch) * sizeof(int32_t));
+  if (planes_total) *planes_total = total;
+  if (planes) {
+    const long long ncopy = total < planes_cap ? total : planes_cap;
+    if (ncopy > 0) std::memcpy(planes, st + off_planes, static_cast<size_t>(ncopy) * sizeof(dpx_plane));
+    if (total > planes_cap)
+      return fail(DPX_ERR_CAPACITY, "plane buffer holds " + std::to_string(planes_cap) + " records, the batch has " + std::to_string(total));
   }
   return DPX_OK;
 }

@@ -881,3 +881,20 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 8 and d["scaling"] == "weak" and d["unit"] == "frames/s"
     assert d["value"] > 0 and abs(d["value"] - 2 * 64 * 8 / (d["ms_per_step"] * 8e-3)) / d["value"] < 0.02
     assert "cpu_baseline" not in d and d["roofline"]["frac"] > 0 and d["parity"].startswith("bit-exact")
+    assert "checked on all 2 rank(s)" in d["parity"]  # every rank ran the oracle spot check, verdicts MIN-reduced
+    assert d["sustained"]["value"] > 0 and d["sustained"]["groups_in_flight"] == 4 and "end_to_end" not in d
+
+
+def test_bench_refuses_to_report_when_a_rank_fails_parity():
+    """DPX_BENCH_FAIL_RANK=1 makes rank 1 report a parity failure: the MIN-reduced verdict must stop rank 0 from printing."""
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, DPX_BENCH_SINGLE_DEVICE="1", DPX_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", DPX_BENCH_FAIL_RANK="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29535", str(root / "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--streams", "4",
+           "--no-cloud-roofline", "--roofline-iters", "5", "--no-sustained"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")], r.stdout
+    assert "parity check failed" in (r.stderr + r.stdout)
