@@ -28,11 +28,13 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-# plane-fit kernel (depth): VALU instructions per pixel / per cell in the ISA and the chip's
-# measured VALU rates in T lane-operations/s (tools/ubench/pk.hip on MI355X: dependent v_mul->v_add pairs at >= 2 waves
-# per SIMD; v_fma_f32)
-VALU_PER_PIXEL, VALU_PER_CELL = 22.0, 1000
+# plane-fit kernel (depth): vector instructions the kernel EXECUTES per pixel / per cell (rocprofv3 SQ_INSTS_VALU* counters:
+# 3 468.6 per wave = per cell, 24.5 of them per pixel) and the chip's measured VALU rates in T lane-operations/s: dependent
+# v_mul -> v_add pairs at >= 2 waves per SIMD, v_fma_f32 (tools/ubench/pk.hip), and the kernel's own instruction mix priced
+# class by class (tools/ubench/mix.hip; profiles/r03_planefit_isa_budget.md: 2.22 SIMD cycles per instruction against 1.77)
+VALU_PER_PIXEL, VALU_PER_CELL = 24.5, 1019
 VALU_PEAK_MULADD_TOPS, VALU_PEAK_FMA_TOPS = 62.7, 39.6
+VALU_PEAK_MIX_TOPS = round(62.7 * 1.77 / 2.22, 1)
 
 
 def dist_env():
@@ -434,8 +436,10 @@ def main():
                          "bytes_per_launch": pf_bytes, "avg_launch_ms": round(pf_ms, 4),
                          "valu": {"lane_ops_per_launch": lane_ops,
                                   "achieved_Tops": round(lane_ops / (pf_ms * 1e-3) / 1e12, 2),
-                                  "measured_peak_Tops": {"mul_add_mix": VALU_PEAK_MULADD_TOPS, "fma": VALU_PEAK_FMA_TOPS},
-                                  "frac_of_mul_add_peak": round(lane_ops / (pf_ms * 1e-3) / (VALU_PEAK_MULADD_TOPS * 1e12), 3)},
+                                  "measured_peak_Tops": {"mul_add": VALU_PEAK_MULADD_TOPS, "fma": VALU_PEAK_FMA_TOPS, "kernel_mix": VALU_PEAK_MIX_TOPS},
+                                  "frac_of_mul_add_peak": round(lane_ops / (pf_ms * 1e-3) / (VALU_PEAK_MULADD_TOPS * 1e12), 3),
+                                  "frac_of_kernel_mix_peak": round(lane_ops / (pf_ms * 1e-3) / (VALU_PEAK_MIX_TOPS * 1e12), 3),
+                                  "budget": "profiles/r03_planefit_isa_budget.md (executed instructions by class x measured issue costs)"},
                          "measured": f"{args.roofline_iters} launches back to back on one stream after the timed region, HIP events on that stream; "
                                      f"{G} distinct input buffers per launch",
                          "in_pipeline": {"avg_launch_ms": round(kms["planefit"], 4), "achieved": round(in_pipe, 1),
