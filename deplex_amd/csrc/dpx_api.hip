@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -98,8 +99,8 @@ struct dpx_handle_s {
     float fx, fy, cx, cy, rx, ry;
     bool ok;
   };
-  std::vector<FdEntry> fd_cache;  // most recently used first
   unsigned int* d_mismatch = nullptr;
+  hipStream_t verify_stream = nullptr;  // the exact-division check runs here, beside whatever the handle has in flight
   // profiling: a ring of event sets, one per process call
   bool profiling = false;
   static constexpr int kProfSlots = 128;
@@ -151,49 +152,85 @@ void free_all(dpx_handle h) {
   for (auto& slot : h->ev)
     for (auto& e : slot)
       if (e) hipEventDestroy(e);
+  if (h->verify_stream) hipStreamDestroy(h->verify_stream);
   if (h->stream) hipStreamDestroy(h->stream);
 }
 
-int device_cus() {  // compute units of the current device (persistent launches size their grids with it)
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    return n;
-  }();
-  return cus;
+int device_cus() {  // compute units of the CURRENT device (persistent launches size their grids with it), cached per device id
+  static std::mutex mu;
+  static std::vector<int> cus;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 256;
+  std::lock_guard<std::mutex> lk(mu);
+  if (static_cast<size_t>(dev) >= cus.size()) cus.resize(static_cast<size_t>(dev) + 1, 0);
+  if (cus[dev] <= 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  return cus[dev];
 }
 
 bool fast_shape(const dpx::Params& prm) {
   return !prm.sheared && (prm.P == 4 || prm.P == 8 || prm.P == 10) && (prm.W % 2 == 0) && prm.C > 0;
 }
 
-// Verifies (once per intrinsics tuple) that the reciprocal-based division of the fast plane-fit kernel returns the
-// IEEE quotient for every numerator this image geometry can produce.  Synchronises the first time a tuple is seen;
-// the last kFdCache tuples are remembered (a stream may alternate between a few cameras).
-constexpr size_t kFdCache = 16;
+// Verifies (once per intrinsics tuple and image shape) that the reciprocal-based division of the fast plane-fit kernel
+// returns the IEEE quotient for every numerator this image geometry can produce.  The verdicts live in ONE process-wide
+// cache (device, W, H and the four floats compared bit for bit, so a NaN tuple matches itself): the slots of a pipeline
+// and every extractor of the same shape share them.  A tuple seen for the first time is checked on a stream of its own
+// and only that stream is waited for — a pipeline_submit() with new intrinsics does not wait for the slot's group in
+// flight (it does block the host for the ~0.2 ms the two check kernels take).
+struct FdKey {
+  int device, W, H;
+  uint32_t fx, fy, cx, cy;
+  bool operator==(const FdKey& o) const { return device == o.device && W == o.W && H == o.H && fx == o.fx && fy == o.fy && cx == o.cx && cy == o.cy; }
+};
+struct FdGlobal {
+  FdKey key;
+  dpx_handle_s::FdEntry e;
+};
+constexpr size_t kFdCache = 64;
+std::mutex g_fd_mu;
+std::vector<FdGlobal> g_fd_cache;  // most recently used first
+
+uint32_t f32_bits(float v) {
+  uint32_t u;
+  std::memcpy(&u, &v, 4);
+  return u;
+}
+
 int prepare_intrinsics(dpx_handle h, float fx, float fy, float cx, float cy, dpx_handle_s::FdEntry* out) {
-  for (size_t i = 0; i < h->fd_cache.size(); ++i) {
-    const auto& e = h->fd_cache[i];
-    if (e.fx == fx && e.fy == fy && e.cx == cx && e.cy == cy) {
-      if (i != 0) std::rotate(h->fd_cache.begin(), h->fd_cache.begin() + i, h->fd_cache.begin() + i + 1);
-      if (out) *out = h->fd_cache[0];
-      return DPX_OK;
-    }
+  const bool fast = fast_shape(h->prm) && !std::getenv("DPX_NO_FASTDIV");
+  const FdKey key{fast ? h->device : -1, fast ? h->W : 0, fast ? h->H : 0, f32_bits(fx), f32_bits(fy), f32_bits(cx), f32_bits(cy)};
+  {
+    std::lock_guard<std::mutex> lk(g_fd_mu);
+    for (size_t i = 0; i < g_fd_cache.size(); ++i)
+      if (g_fd_cache[i].key == key) {
+        if (i != 0) std::rotate(g_fd_cache.begin(), g_fd_cache.begin() + i, g_fd_cache.begin() + i + 1);
+        if (out) *out = g_fd_cache[0].e;
+        return DPX_OK;
+      }
   }
   dpx_handle_s::FdEntry e{fx, fy, cx, cy, 1.0f / fx, 1.0f / fy, false};
-  if (fast_shape(h->prm) && std::isfinite(e.rx) && std::isfinite(e.ry) && !std::getenv("DPX_NO_FASTDIV")) {
+  if (fast && std::isfinite(e.rx) && std::isfinite(e.ry)) {
+    if (!h->verify_stream) DPX_HIP(hipStreamCreateWithFlags(&h->verify_stream, hipStreamNonBlocking));
     if (!h->d_mismatch) DPX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_mismatch), sizeof(unsigned int)));
-    DPX_HIP(hipMemsetAsync(h->d_mismatch, 0, sizeof(unsigned int), h->stream));
+    hipStream_t vs = h->verify_stream;
+    DPX_HIP(hipMemsetAsync(h->d_mismatch, 0, sizeof(unsigned int), vs));
     const long long tx = static_cast<long long>(h->W) * 65536, ty = static_cast<long long>(h->H) * 65536;
-    hipLaunchKernelGGL(dpx::k_verify_fastdiv, dim3(static_cast<unsigned>((tx + 255) / 256)), dim3(256), 0, h->stream, h->W, cx, fx, e.rx, h->d_mismatch);
-    hipLaunchKernelGGL(dpx::k_verify_fastdiv, dim3(static_cast<unsigned>((ty + 255) / 256)), dim3(256), 0, h->stream, h->H, cy, fy, e.ry, h->d_mismatch);
+    hipLaunchKernelGGL(dpx::k_verify_fastdiv, dim3(static_cast<unsigned>((tx + 255) / 256)), dim3(256), 0, vs, h->W, cx, fx, e.rx, h->d_mismatch);
+    hipLaunchKernelGGL(dpx::k_verify_fastdiv, dim3(static_cast<unsigned>((ty + 255) / 256)), dim3(256), 0, vs, h->H, cy, fy, e.ry, h->d_mismatch);
     unsigned int mism = 1;
-    DPX_HIP(hipMemcpyAsync(&mism, h->d_mismatch, sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
-    DPX_HIP(hipStreamSynchronize(h->stream));
+    DPX_HIP(hipMemcpyAsync(&mism, h->d_mismatch, sizeof(unsigned int), hipMemcpyDeviceToHost, vs));
+    DPX_HIP(hipStreamSynchronize(vs));
     e.ok = (mism == 0);
   }
-  if (h->fd_cache.size() >= kFdCache) h->fd_cache.pop_back();
-  h->fd_cache.insert(h->fd_cache.begin(), e);
+  {
+    std::lock_guard<std::mutex> lk(g_fd_mu);
+    if (g_fd_cache.size() >= kFdCache) g_fd_cache.pop_back();
+    g_fd_cache.insert(g_fd_cache.begin(), FdGlobal{key, e});
+  }
   if (out) *out = e;
   return DPX_OK;
 }

@@ -73,6 +73,7 @@ inline std::string read_grey16(const char* path, Image& out) {
     const unsigned char* type = &file[pos + 4];
     const unsigned char* data = &file[pos + 8];
     if (len > file.size() || pos + 12 + len > file.size()) return "truncated chunk";
+    if (pos == 8 && std::memcmp(type, "IHDR", 4)) return "first chunk is not IHDR";  // (stb_image.h: "first not IHDR")
     if (!std::memcmp(type, "IHDR", 4)) {
       if (len != 13) return "bad IHDR";
       W = be32(data); H = be32(data + 4);
@@ -121,10 +122,35 @@ inline std::string read_grey16(const char* path, Image& out) {
     ph[p] = H > ps.y0 ? (H - ps.y0 + ps.dy - 1) / ps.dy : 0;
     if (pw[p] && ph[p]) total += ph[p] * (1 + (pw[p] * bits_pp + 7) / 8);
   }
-  std::vector<unsigned char> raw(total);
-  uLongf dlen = static_cast<uLongf>(total);
-  const int zr = uncompress(raw.data(), &dlen, idat.data(), static_cast<uLong>(idat.size()));
-  if (zr != Z_OK || dlen != total) return "corrupt image data";
+  // A header can claim any size: deflate expands at most 1032 : 1, so more pixels than the IDAT bytes can encode mean a
+  // corrupt (or hostile) file — refuse before allocating gigabytes for a 100-byte file.
+  if (total > idat.size() * 1032ull + 65536ull) return "corrupt image data";
+  // Inflate with the loader's tolerance (utils/depth_image.cpp:30-40 -> stbi_load_16, stb_image.h:4626): the decoded stream
+  // may be LONGER than the image needs (extra bytes are ignored) and its Adler-32 trailer is not checked; the output
+  // buffer grows with the data instead of being sized from the header.
+  std::vector<unsigned char> raw;
+  {
+    z_stream zs;
+    std::memset(&zs, 0, sizeof(zs));
+    if (inflateInit(&zs) != Z_OK) return "corrupt image data";
+    zs.next_in = idat.data();
+    zs.avail_in = static_cast<uInt>(idat.size());
+    unsigned char chunk[65536];
+    int zr = Z_OK;
+    while (raw.size() < total) {
+      zs.next_out = chunk;
+      zs.avail_out = sizeof(chunk);
+      zr = inflate(&zs, Z_NO_FLUSH);
+      const size_t got = sizeof(chunk) - zs.avail_out;
+      const size_t take = got < total - raw.size() ? got : total - raw.size();
+      raw.insert(raw.end(), chunk, chunk + take);
+      if (zr == Z_STREAM_END) break;
+      if (zr == Z_DATA_ERROR && raw.size() >= total) break;  // (a bad checksum after complete data: stb does not look at it)
+      if (zr != Z_OK || (got == 0 && zs.avail_in == 0)) break;
+    }
+    inflateEnd(&zs);
+    if (raw.size() < total) return "corrupt image data";
+  }
   out.width = static_cast<int32_t>(W);
   out.height = static_cast<int32_t>(H);
   out.grey.assign(static_cast<size_t>(W) * H, 0);

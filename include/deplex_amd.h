@@ -164,7 +164,10 @@ int dpx_process_pcd_batch_device(dpx_handle h, const void* d_xyz, int32_t batch,
  * sequence per group (the GPU executes only a handful of kernels concurrently and a launch per small batch leaves the
  * chip under-filled at its start and end; group = 1 restores launch-per-submission).  Submissions must all have the
  * batch size given at creation.
- * submit() is asynchronous on device pointers; results of a submission are complete after dpx_pipeline_sync() (which
+ * submit() is asynchronous on device pointers (the first submission with an intrinsics tuple the process has not seen
+ * for this image shape blocks the host for the ~0.2 ms of its exact-division check, on a stream of its own — it does not
+ * wait for the slot's group in flight; dpx_prepare_intrinsics() moves that ahead of time); results of a submission are
+ * complete after dpx_pipeline_sync() (which
  * also flushes a partially filled group).  The caller must not reuse d_depth / d_labels of a submission before that.
  * dpx_pipeline_slot() exposes the per-slot handle (frames of a slot = its group's submissions back to back). */
 int dpx_pipeline_create(const dpx_config* cfg, int32_t image_height, int32_t image_width, int32_t batch, int32_t device,

@@ -260,3 +260,20 @@ def test_png_reader_follows_the_reference_loader(tmp_path):
     (tmp_path / "trunc.png").write_bytes((tmp_path / "g16.png").read_bytes()[:200])
     with pytest.raises(DeplexError, match="Error: Couldn't read image"):
         utils._load_u16(tmp_path / "trunc.png")
+    # the loader's tolerances (stb_image.h:4626): a deflate stream LONGER than the image needs and a wrong Adler-32
+    # trailer are accepted; a header that claims far more pixels than the IDAT bytes can encode is refused before any
+    # allocation; IHDR has to be the first chunk
+    def chunk(t, d): return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    sig, raw = b"\x89PNG\r\n\x1a\n", b"".join(b"\x00" + g16[r].astype(">u2").tobytes() for r in range(h))
+    ihdr = chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 0, 0, 0, 0))
+    (tmp_path / "long.png").write_bytes(sig + ihdr + chunk(b"IDAT", zlib.compress(raw + b"\x00" * 37)) + chunk(b"IEND", b""))
+    assert np.array_equal(utils._load_u16(tmp_path / "long.png"), g16)
+    z = bytearray(zlib.compress(raw)); z[-1] ^= 0x5A
+    (tmp_path / "adler.png").write_bytes(sig + ihdr + chunk(b"IDAT", bytes(z)) + chunk(b"IEND", b""))
+    assert np.array_equal(utils._load_u16(tmp_path / "adler.png"), g16)
+    huge = chunk(b"IHDR", struct.pack(">IIBBBBB", 16384, 16384, 16, 6, 0, 0, 0))
+    (tmp_path / "bomb.png").write_bytes(sig + huge + chunk(b"IDAT", zlib.compress(b"\x00" * 64)) + chunk(b"IEND", b""))
+    (tmp_path / "noihdr.png").write_bytes(sig + chunk(b"gAMA", struct.pack(">I", 45455)) + ihdr + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    for bad in ("bomb.png", "noihdr.png"):
+        with pytest.raises(DeplexError, match="Error: Couldn't read image"):
+            utils._load_u16(tmp_path / bad)
