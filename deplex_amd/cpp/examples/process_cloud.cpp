@@ -34,6 +34,26 @@ int main(int argc, char** argv) {
     const double us = std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t0).count() / NUMBER_OF_RUNS;
     std::cout << "planes " << *std::max_element(labels.begin(), labels.end()) << " labels " << labels.size() << " mean_us " << us
               << " fps " << 1e6 / us << " fitted " << algorithm.planes().size() << "\n";
+    // batched depth entry points: pixel labels, the cell-level form expanded on the host, and two shards on one device
+    {
+      const int B = 5;
+      std::vector<uint16_t> frames(static_cast<size_t>(B) * h * w);
+      for (int k = 0; k < B; ++k) std::copy(raw.begin(), raw.end(), frames.begin() + static_cast<size_t>(k) * h * w);
+      deplex::PlaneExtractor batch(h, w, config, B);
+      const std::vector<int32_t> pix = batch.processDepthBatch(frames.data(), B, K[0], K[4], K[2], K[5]);
+      const auto cells = batch.processDepthBatchCells(frames.data(), B, K[0], K[4], K[2], K[5]);
+      std::vector<int32_t> expanded(pix.size());
+      if (dpx_expand_cell_labels(h, w, config.patch_size, cells.cell_labels.data(), B, expanded.data()) != DPX_OK) throw std::runtime_error(dpx_last_error());
+      int32_t* pinned = static_cast<int32_t*>(dpx_host_alloc(pix.size() * sizeof(int32_t)));
+      if (!pinned) throw std::runtime_error(dpx_last_error());
+      deplex::ShardedExtractor sharded(h, w, {0, 0}, config, 2);
+      sharded.processDepthBatch(frames.data(), B, K[0], K[4], K[2], K[5], pinned);
+      const bool same = std::equal(pix.begin(), pix.end(), pinned) && expanded == pix && std::equal(labels.begin(), labels.end(), pix.begin());
+      dpx_host_free(pinned);
+      std::cout << "batch " << B << " cells_equal_pixels_equal_sharded " << (same ? 1 : 0) << " planes_frame0 " << cells.n_planes[0] << " total "
+                << cells.planes.size() << "\n";
+      if (!same) return 1;
+    }
     // the reference's throwing cases
     try {
       deplex::config::Config bad;

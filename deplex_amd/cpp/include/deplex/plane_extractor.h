@@ -7,7 +7,10 @@
 // overload is enabled automatically when <Eigen/Core> is on the include path.
 #pragma once
 #include <cstdint>
+#include <algorithm>
 #include <stdexcept>
+#include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -65,6 +68,36 @@ class PlaneExtractor {
     if (dpx_process_depth_batch(h_, depth, batch, fx, fy, cx, cy, labels.data()) != DPX_OK) throw std::runtime_error(dpx_last_error());
     return labels;
   }
+  /** The same with caller-provided output (e.g. a slice of a page-locked buffer, dpx_host_alloc). */
+  void processDepthBatch(uint16_t const* depth, int32_t batch, float fx, float fy, float cx, float cy, int32_t* labels) {
+    if (dpx_process_depth_batch(h_, depth, batch, fx, fy, cx, cy, labels) != DPX_OK) throw std::runtime_error(dpx_last_error());
+  }
+  /** Cell-level output of the same computation (what the reference holds before toImageLabels, plane_extractor.cpp:455-470):
+   *  the merged 1-based label of every cell, batch x nv x nh, and the batch's plane records packed frame after frame
+   *  (n_planes[f] records for frame f).  80x fewer bytes cross PCIe than with the pixel map. */
+  struct CellResult {
+    std::vector<int32_t> cell_labels;
+    std::vector<int32_t> n_planes;
+    std::vector<dpx_plane> planes;
+  };
+  CellResult processDepthBatchCells(uint16_t const* depth, int32_t batch, float fx, float fy, float cx, float cy) {
+    int32_t nh = 0, nv = 0;
+    if (dpx_grid_dims(h_, &nh, &nv) != DPX_OK) throw std::runtime_error(dpx_last_error());
+    CellResult r;
+    r.cell_labels.resize(static_cast<size_t>(batch) * nh * nv);
+    r.n_planes.resize(static_cast<size_t>(batch));
+    r.planes.resize(static_cast<size_t>(batch) * 64);
+    int64_t total = 0;
+    int rc = dpx_process_depth_batch_cells(h_, depth, batch, fx, fy, cx, cy, r.cell_labels.data(), r.n_planes.data(), r.planes.data(),
+                                           static_cast<int64_t>(r.planes.size()), &total);
+    if (rc == DPX_ERR_CAPACITY) {  // more than 64 planes per frame on average: once more with the reported size
+      r.planes.resize(static_cast<size_t>(total));
+      rc = dpx_process_depth_batch_cells(h_, depth, batch, fx, fy, cx, cy, r.cell_labels.data(), r.n_planes.data(), r.planes.data(), total, &total);
+    }
+    if (rc != DPX_OK) throw std::runtime_error(dpx_last_error());
+    r.planes.resize(static_cast<size_t>(total));
+    return r;
+  }
   /** Fitted planes of frame `frame` of the last call (the reference keeps them private, plane_extractor.cpp:222). */
   std::vector<dpx_plane> planes(int32_t frame = 0) {
     int32_t n = 0;
@@ -74,9 +107,57 @@ class PlaneExtractor {
     return out;
   }
   dpx_handle handle() const { return h_; }
+  int32_t height() const { return height_; }
+  int32_t width() const { return width_; }
 
  private:
   dpx_handle h_ = nullptr;
   int32_t height_, width_;
+};
+
+/** A batch of HOST frames over several GPUs of one node (not in the reference, which is single-threaded): frames are
+ *  independent (an extractor holds only per-call scratch, plane_extractor.cpp:281,428), so the batch is cut into contiguous
+ *  ranges frames[g*B/G, (g+1)*B/G), one per entry of `devices` (a device may be listed more than once), each processed by
+ *  its own host thread through its own extractor in chunks of max_batch frames; the label maps land in the caller's
+ *  (ideally page-locked) output at the range's offset.  No exchange between devices. */
+class ShardedExtractor {
+ public:
+  ShardedExtractor(int32_t image_height, int32_t image_width, std::vector<int32_t> const& devices, config::Config config = config::Config(),
+                   int32_t max_batch = 64)
+      : height_(image_height), width_(image_width), max_batch_(max_batch) {
+    if (devices.empty()) throw std::runtime_error("ShardedExtractor needs at least one device");
+    for (int32_t d : devices) shards_.emplace_back(image_height, image_width, config, max_batch, d);
+  }
+  static std::pair<int64_t, int64_t> shardRange(int64_t n_frames, int64_t rank, int64_t world) {
+    return {n_frames * rank / world, n_frames * (rank + 1) / world};
+  }
+  void processDepthBatch(uint16_t const* depth, int64_t batch, float fx, float fy, float cx, float cy, int32_t* labels) {
+    const size_t n = static_cast<size_t>(height_) * width_;
+    const int64_t world = static_cast<int64_t>(shards_.size());
+    std::vector<std::thread> threads;
+    std::vector<std::string> errors(shards_.size());
+    for (int64_t g = 0; g < world; ++g) {
+      const auto range = shardRange(batch, g, world);
+      if (range.second <= range.first) continue;
+      threads.emplace_back([&, g, range] {
+        try {
+          for (int64_t s = range.first; s < range.second; s += max_batch_) {
+            const int32_t b = static_cast<int32_t>(std::min<int64_t>(max_batch_, range.second - s));
+            shards_[static_cast<size_t>(g)].processDepthBatch(depth + static_cast<size_t>(s) * n, b, fx, fy, cx, cy, labels + static_cast<size_t>(s) * n);
+          }
+        } catch (std::exception const& e) {
+          errors[static_cast<size_t>(g)] = e.what();
+        }
+      });
+    }
+    for (auto& t : threads) t.join();
+    for (auto const& e : errors)
+      if (!e.empty()) throw std::runtime_error(e);
+  }
+  size_t shards() const { return shards_.size(); }
+
+ private:
+  int32_t height_, width_, max_batch_;
+  std::vector<PlaneExtractor> shards_;
 };
 }  // namespace deplex

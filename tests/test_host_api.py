@@ -123,7 +123,7 @@ def build_cpp_example(tmp_path):
     exe = tmp_path / "process_cloud"
     cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I", str(ROOT / "deplex_amd" / "cpp" / "include"),
            str(ROOT / "deplex_amd" / "cpp" / "examples" / "process_cloud.cpp"), "-L", str(ROOT / "deplex_amd" / "lib"),
-           "-ldeplex_amd", f"-Wl,-rpath,{ROOT / 'deplex_amd' / 'lib'}", "-o", str(exe)]
+           "-ldeplex_amd", "-pthread", f"-Wl,-rpath,{ROOT / 'deplex_amd' / 'lib'}", "-o", str(exe)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return exe
