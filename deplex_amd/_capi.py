@@ -69,6 +69,7 @@ SYMBOLS = {
     "dpx_process_pcd_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "dpx_process_depth_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "dpx_process_depth_batch_cells": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "dpx_get_packed_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "dpx_expand_cell_labels": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "dpx_host_alloc": (C.c_void_p, [C.c_size_t]),
     "dpx_host_free": (None, [C.c_void_p]),

@@ -86,15 +86,11 @@ class PlaneExtractor {
     CellResult r;
     r.cell_labels.resize(static_cast<size_t>(batch) * nh * nv);
     r.n_planes.resize(static_cast<size_t>(batch));
-    r.planes.resize(static_cast<size_t>(batch) * 64);
     int64_t total = 0;
-    int rc = dpx_process_depth_batch_cells(h_, depth, batch, fx, fy, cx, cy, r.cell_labels.data(), r.n_planes.data(), r.planes.data(),
-                                           static_cast<int64_t>(r.planes.size()), &total);
-    if (rc == DPX_ERR_CAPACITY) {  // more than 64 planes per frame on average: once more with the reported size
-      r.planes.resize(static_cast<size_t>(total));
-      rc = dpx_process_depth_batch_cells(h_, depth, batch, fx, fy, cx, cy, r.cell_labels.data(), r.n_planes.data(), r.planes.data(), total, &total);
-    }
-    if (rc != DPX_OK) throw std::runtime_error(dpx_last_error());
+    if (dpx_process_depth_batch_cells(h_, depth, batch, fx, fy, cx, cy, r.cell_labels.data(), r.n_planes.data(), nullptr, 0, &total) != DPX_OK)
+      throw std::runtime_error(dpx_last_error());
+    r.planes.resize(static_cast<size_t>(total));  // (sized from the count: one copy out of the handle's staging)
+    if (dpx_get_packed_planes(h_, r.planes.data(), total, nullptr) != DPX_OK) throw std::runtime_error(dpx_last_error());
     r.planes.resize(static_cast<size_t>(total));
     return r;
   }

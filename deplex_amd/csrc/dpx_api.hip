@@ -86,6 +86,8 @@ struct dpx_handle_s {
   uint32_t* d_bin_off = nullptr;              // [B][nb + 1]
   uint32_t* d_gqpos = nullptr;                // tier 0: [B][C]
   char* h_cells_stage = nullptr;              // cell-level output: page-locked staging the device writes into
+  long long cells_stage_total = -1;           // plane records the staging holds from the last cell-level call (-1: none)
+  size_t cells_stage_planes_off = 0;
   uint8_t* d_gflags = nullptr;
   uint8_t* d_gowner = nullptr;
   uint32_t* d_gqueue = nullptr;
@@ -1050,7 +1052,7 @@ int dpx_process_depth_batch_cells(dpx_handle h, const uint16_t* depth, int32_t b
     DPX_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->h_cells_stage), off_planes + pack_cap * sizeof(dpx_plane), hipHostMallocDefault));
   }
   char* st = h->h_cells_stage;
-  const bool want_planes = planes != nullptr;
+  const bool want_planes = planes != nullptr || n_planes != nullptr || planes_total != nullptr;  // (packed whenever counts are asked for: dpx_get_packed_planes)
   DPX_HIP(hipMemcpyAsync(h->d_in, depth, N * batch * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
   h->no_pixel_labels = true;
   rc = run_pipeline(h, h->d_in, true, batch, fx, fy, cx, cy, h->d_labels, h->stream);
@@ -1066,6 +1068,8 @@ int dpx_process_depth_batch_cells(dpx_handle h, const uint16_t* depth, int32_t b
   DPX_HIP(hipStreamSynchronize(h->stream));
   std::memcpy(cell_labels, st, static_cast<size_t>(words) * sizeof(int32_t));
   const long long total = *reinterpret_cast<const long long*>(st + off_total);
+  h->cells_stage_total = want_planes ? total : -1;
+  h->cells_stage_planes_off = off_planes;
   if (n_planes) std::memcpy(n_planes, st + off_counts, static_cast<size_t>(batch) * sizeof(int32_t));
   if (planes_total) *planes_total = total;
   if (planes) {
@@ -1074,6 +1078,18 @@ int dpx_process_depth_batch_cells(dpx_handle h, const uint16_t* depth, int32_t b
     if (total > planes_cap)
       return fail(DPX_ERR_CAPACITY, "plane buffer holds " + std::to_string(planes_cap) + " records, the batch has " + std::to_string(total));
   }
+  return DPX_OK;
+}
+
+int dpx_get_packed_planes(dpx_handle h, dpx_plane* planes, int64_t planes_cap, int64_t* planes_total) {
+  if (!h) return fail(DPX_ERR_ARG, "null handle");
+  if (!h->h_cells_stage || h->cells_stage_total < 0) return fail(DPX_ERR_ARG, "no cell-level call with plane counts precedes this one");
+  if (planes_total) *planes_total = h->cells_stage_total;
+  if (planes_cap < 0 || (planes_cap > 0 && !planes)) return fail(DPX_ERR_ARG, "bad plane buffer");
+  const long long ncopy = h->cells_stage_total < planes_cap ? h->cells_stage_total : planes_cap;
+  if (ncopy > 0) std::memcpy(planes, h->h_cells_stage + h->cells_stage_planes_off, static_cast<size_t>(ncopy) * sizeof(dpx_plane));
+  if (h->cells_stage_total > planes_cap)
+    return fail(DPX_ERR_CAPACITY, "plane buffer holds " + std::to_string(planes_cap) + " records, the batch has " + std::to_string(h->cells_stage_total));
   return DPX_OK;
 }
 

@@ -141,17 +141,12 @@ class PlaneExtractor:
                                                                  None, None, 0, None))
             return out.reshape(b, self.nv, self.nh), None
         counts = np.zeros(max(b, 1), dtype=np.int32)
-        cap = max(64 * b, 1)
         total = C.c_int64()
-        while True:
-            recs = np.zeros(cap, dtype=_capi.PLANE_DTYPE)
-            rc = _capi.lib().dpx_process_depth_batch_cells(self._h, depth.ctypes.data, b, fx, fy, cx, cy, out.ctypes.data,
-                                                          counts.ctypes.data, recs.ctypes.data, cap, C.byref(total))
-            if rc == _capi.DPX_ERR_CAPACITY and total.value > cap:  # (rare: more than 64 planes per frame on average)
-                cap = int(total.value)
-                continue
-            _capi.check(rc)
-            break
+        _capi.check(_capi.lib().dpx_process_depth_batch_cells(self._h, depth.ctypes.data, b, fx, fy, cx, cy, out.ctypes.data,
+                                                             counts.ctypes.data, None, 0, C.byref(total)))
+        recs = np.zeros(max(int(total.value), 1), dtype=_capi.PLANE_DTYPE)  # (sized from the count: one copy out of the staging)
+        _capi.check(_capi.lib().dpx_get_packed_planes(self._h, recs.ctypes.data, int(total.value), None))
+        recs = recs[: int(total.value)]
         offs = np.concatenate([[0], np.cumsum(counts[:b])])
         return out.reshape(b, self.nv, self.nh), [recs[offs[k]:offs[k + 1]] for k in range(b)]
 

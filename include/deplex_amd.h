@@ -139,6 +139,10 @@ int dpx_process_depth_batch(dpx_handle h, const uint16_t* depth, int32_t batch, 
 int dpx_process_depth_batch_cells(dpx_handle h, const uint16_t* depth, int32_t batch, float fx, float fy, float cx,
                                   float cy, int32_t* cell_labels, int32_t* n_planes, dpx_plane* planes,
                                   int64_t planes_cap, int64_t* planes_total);
+/* The packed plane records of the LAST dpx_process_depth_batch_cells call on this handle that asked for counts (n_planes or
+ * planes_total non-NULL), from the handle's page-locked staging — for callers that size their buffer from *planes_total
+ * first (pass planes = NULL to the processing call, then call this once).  Same capacity rule. */
+int dpx_get_packed_planes(dpx_handle h, dpx_plane* planes, int64_t planes_cap, int64_t* planes_total);
 /* Impl::toImageLabels (plane_extractor.cpp:455-470) on the host, for callers of the cell-level form that want a pixel
  * map after all: labels[f][row][col] = cell_labels[f][row / P][col / P] (0 outside the nv*P x nh*P grid; P = the
  * stored patch size min(patch_size, H, W), nh = W / patch_size, nv = H / patch_size).  Plain C loop, no device. */
