@@ -464,7 +464,10 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
     constexpr int kSpecMax = 8;  // cells of a speculative grow: one relative cell code per byte of a 64-bit register pair
     // Rounds with fewer events take the first one on its own (see there): a sweep round costs about what four single
     // events cost, and on average 60 % of a round's events are committed before it stops.
-    constexpr int kSweepMinEvents = 6;  // cells of a speculative grow (<= 8): one relative cell code per byte of a 64-bit register pair
+#ifndef DPX_SWEEP_MIN
+#define DPX_SWEEP_MIN 6
+#endif
+    constexpr int kSweepMinEvents = DPX_SWEEP_MIN;
     uint32_t* candc = reinterpret_cast<uint32_t*>(smem + lay.grow_x);
     uint32_t* bclaim = candc + nb;
     uint32_t* ctab = bclaim + nb;
@@ -829,7 +832,13 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
             const int cs = part ? static_cast<int>(c) : 0;
             // How far speculation pays depends on how many events can be committed together: a pop costs about as much as a
             // step of the wave-wide BFS (which takes 16 cells).
-            const int maxpops = nev >= 8 ? kSpecMax : (kSpecMax < 4 ? kSpecMax : 4);
+#ifndef DPX_MAXPOPS
+#define DPX_MAXPOPS kSpecMax
+#endif
+#ifndef DPX_MAXPOPS_SMALL
+#define DPX_MAXPOPS_SMALL 4
+#endif
+            const int maxpops = nev >= 8 ? DPX_MAXPOPS : DPX_MAXPOPS_SMALL;
             const unsigned long long t_sp0 = DPX_STAMP();
             while (__ballot(act)) {
               if (DBG) ++n_pops;

@@ -358,6 +358,21 @@ def test_baseline_config_5_full_size(D, oracle, batch):
     _full_size_config(D, oracle, 2160, 3840, batch, 4)
 
 
+@pytest.mark.parametrize("h,w,seed,ov", [
+    (960, 1280, 6, {"histogram_bins_per_coord": 60, "min_region_growing_cells_activated": 1, "min_region_growing_candidate_size": 1}),
+    (960, 1280, 2, {"histogram_bins_per_coord": 33, "min_region_growing_cells_activated": 2, "min_cos_angle_merge": 0.8}),
+    (2160, 3840, 2, {"histogram_bins_per_coord": 40, "min_region_growing_candidate_size": 1}),
+    (1080, 1920, 0, {"histogram_bins_per_coord": 7, "min_region_growing_cells_activated": 8})])
+def test_sweep_rounds_corner_configs(D, oracle, h, w, seed, ov):
+    """The sweep rounds of the large-frame tiers (dpx_regions2.h) away from the default configuration: more than 256
+    non-empty bins (bins beyond the four register-resident chunks are read from the list), single-cell grows that ARE
+    segment candidates (min_region_growing_cells_activated = 1: every committed lane writes a candidate record), a
+    candidate size of 1 (the loop runs until the histogram is empty), few bins (many cells per bin, long dead runs in the
+    seed lists) and a wide merge cone; tier 1 (1280x960), tier 0 (4K) and the 1920x1080 frame between them."""
+    depth = synth.synth_depth(h, w, seed=seed)[None]
+    full_compare(D, oracle, depth, synth.intrinsics_for(h, w), oracle.default_config(**ov))
+
+
 def test_fast_division_is_verified(D):
     """The reciprocal division of the fast plane-fit kernel is accepted only after an exhaustive device-side check
     against IEEE division for the frame geometry; the fixtures' intrinsics (including ICL's negative fy) pass it."""
