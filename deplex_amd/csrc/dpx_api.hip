@@ -1416,6 +1416,16 @@ int dpx_pipeline_submit_depth(dpx_pipeline p, const void* d_depth, int32_t batch
   return pipeline_submit(p, d_depth, true, batch, fx, fy, cx, cy, d_labels);
 }
 
+int dpx_pipeline_submit_depth_many(dpx_pipeline p, int32_t n, const void* const* d_depth, int32_t batch, float fx, float fy, float cx,
+                                   float cy, void* const* d_labels) {
+  if (n < 0 || (n > 0 && (!d_depth || !d_labels))) return fail(DPX_ERR_ARG, "bad submission list");
+  for (int32_t i = 0; i < n; ++i) {
+    const int rc = pipeline_submit(p, d_depth[i], true, batch, fx, fy, cx, cy, d_labels[i]);
+    if (rc) return rc;
+  }
+  return DPX_OK;
+}
+
 int dpx_pipeline_submit_pcd(dpx_pipeline p, const void* d_xyz, int32_t batch, void* d_labels) {
   return pipeline_submit(p, d_xyz, false, batch, 1.f, 1.f, 0.f, 0.f, d_labels);
 }

@@ -286,6 +286,15 @@ class Pipeline:
     def submit_depth(self, d_depth_ptr: int, batch: int, fx, fy, cx, cy, d_labels_ptr: int) -> None:
         _capi.check(_capi.lib().dpx_pipeline_submit_depth(self._p, d_depth_ptr, batch, fx, fy, cx, cy, d_labels_ptr))
 
+    def submit_depth_many(self, d_depth_ptrs, batch: int, fx, fy, cx, cy, d_labels_ptrs) -> None:
+        """len(d_depth_ptrs) submissions in one call (dpx_pipeline_submit_depth_many): same order and grouping as single calls."""
+        n = len(d_depth_ptrs)
+        if n != len(d_labels_ptrs):
+            raise ValueError("one output buffer per input buffer")
+        ins = (C.c_void_p * n)(*[int(p) for p in d_depth_ptrs])
+        outs = (C.c_void_p * n)(*[int(p) for p in d_labels_ptrs])
+        _capi.check(_capi.lib().dpx_pipeline_submit_depth_many(self._p, n, ins, batch, fx, fy, cx, cy, outs))
+
     def submit_pcd(self, d_xyz_ptr: int, batch: int, d_labels_ptr: int) -> None:
         """Organised clouds (float32 [batch][H*W][3]) in device memory, the reference API's own input form."""
         _capi.check(_capi.lib().dpx_pipeline_submit_pcd(self._p, d_xyz_ptr, batch, d_labels_ptr))

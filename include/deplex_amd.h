@@ -179,6 +179,10 @@ int dpx_pipeline_create(const dpx_config* cfg, int32_t image_height, int32_t ima
 void dpx_pipeline_destroy(dpx_pipeline p);
 int dpx_pipeline_submit_depth(dpx_pipeline p, const void* d_depth, int32_t batch, float fx, float fy, float cx, float cy,
                               void* d_labels);
+/* n submissions in one call (same batch size and intrinsics, one input and one output buffer each): what a caller that
+ * already holds several batches does instead of n calls — the order and the grouping are those of n single calls. */
+int dpx_pipeline_submit_depth_many(dpx_pipeline p, int32_t n, const void* const* d_depth, int32_t batch, float fx, float fy,
+                                   float cx, float cy, void* const* d_labels);
 /* The same for organised clouds (float32 [batch][H*W][3], the input of PlaneExtractor::process, plane_extractor.h:48).
  * A group holds one input form; switching forms closes the open group first. */
 int dpx_pipeline_submit_pcd(dpx_pipeline p, const void* d_xyz, int32_t batch, void* d_labels);
