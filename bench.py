@@ -44,8 +44,12 @@ def dist_env():
 # The other BASELINE.json configs as bench lines (parity-test cases first, tests/test_gpu_parity.py::test_baseline_config_*):
 #   --workload synth1280 = configs[2] (1280x960, batch 256), synth640 = one GPU's share of configs[3] (640x480, 512 of the
 #   4096 frames), synth4k = one GPU's share of configs[4] (3840x2160, 8 of the 64 frames).  A step is one whole batch.
-BIG_WORKLOADS = {"synth1280": dict(batch=256, unique=8, steps=20, warmup=3), "synth640": dict(batch=512, unique=16, steps=40, warmup=4),
-                 "synth4k": dict(batch=8, unique=4, steps=10, warmup=2)}
+# `streams` = whole batches in flight (pipeline slots, one launch sequence each): region growing of a large frame is a
+# latency-bound sequence on one wave, so a stream of batches gains from depth until the chip-wide kernels (plane fit,
+# seed-list sort, tails, label expansion) fill the time: 1280x960 x 256: 101 k / 157 k / 197 k frames/s with 2 / 4 / 8
+# batches in flight; 3840x2160 x 8: 0.85 k / 1.6 k / 3.0 k (8 in flight = the 64 frames of configs[4] on this one GPU).
+BIG_WORKLOADS = {"synth1280": dict(batch=256, unique=8, steps=32, warmup=8, streams=8), "synth640": dict(batch=512, unique=16, steps=40, warmup=4, streams=4),
+                 "synth4k": dict(batch=8, unique=4, steps=24, warmup=8, streams=8)}
 
 
 def make_workload(name: str, batch: int, rank: int, part: int = 0, parts: int = 1, unique: int = 0):
@@ -174,7 +178,7 @@ def main():
     import deplex_amd as D
 
     long_run = args.steps >= 100
-    S = args.streams if args.streams > 0 else (2 if big else (4 if long_run else 16))  # groups in flight (pipeline slots), one stream each
+    S = args.streams if args.streams > 0 else (big["streams"] if big else (4 if long_run else 16))  # groups in flight (pipeline slots), one stream each
     G = max(1, min(32, args.group)) if args.group > 0 else (1 if big else (8 if long_run else 5))
     if big and args.inputs == 8:
         args.inputs = 2

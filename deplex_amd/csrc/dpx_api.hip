@@ -69,6 +69,8 @@ struct dpx_handle_s {
   unsigned long long* d_res = nullptr;  // diagnostic (DPX_RESIDENCY=1): workgroup lifetimes of the three region launches
   float4* d_lds_img = nullptr;          // split region kernel: LDS image per frame
   bool regions_split = false;
+  bool stream_mode = false;   // slot of a dpx_pipeline: several batches in flight, so the LDS a frame's grow wave holds decides throughput
+  bool tier0_split = false;   // tier 0 as three launches with a one-wave grow launch (mid-size frames in stream mode)
   float* d_mse_c = nullptr;
   uint32_t* d_cand_grow = nullptr;
   bool no_pixel_labels = false;  // set for the duration of a cell-level call: the label expansion launch is left out
@@ -475,6 +477,10 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   rx.frames_per_out = per_sub;
   for (int j = 0; j < dpx::kMaxGroup; ++j) rx.labels_out[j] = (fuse_labels && j < nsub) ? subs[j].d_labels : nullptr;
   if (skip_r) {
+  } else if (h->regions_tier == 0 && h->tier0_split && !h->d_dbg) {
+    hipLaunchKernelGGL((dpx::k_regions2<0, false, 1>), dim3(batch), dim3(dpx::kRT), h->lds2_p1, s, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<0, false, 2>), dim3(batch), dim3(64), h->lds2_p2, s, prm, rb, rx);
+    hipLaunchKernelGGL((dpx::k_regions2<0, false, 3>), dim3(batch), dim3(dpx::kTailRT), h->lds2_p3, s, prm, rb, rx);
   } else if (h->regions_tier == 1 && h->regions_split && !h->d_dbg) {
     hipLaunchKernelGGL((dpx::k_regions2<1, false, 1>), dim3(batch), dim3(dpx::kRT), h->lds2_p1, s, prm, rb, rx);
     hipLaunchKernelGGL((dpx::k_regions2<1, false, 2>), dim3(batch), dim3(64), h->lds2_p2, s, prm, rb, rx);
@@ -773,8 +779,16 @@ int dpx_config_from_ini(const char* path, dpx_config* cfg) {
   return DPX_OK;
 }
 
+static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t image_width, int32_t max_batch, int32_t device,
+                         bool stream_mode, dpx_handle* out);
+
 int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width, int32_t max_batch, int32_t device,
                dpx_handle* out) {
+  return create_handle(cfg, image_height, image_width, max_batch, device, false, out);
+}
+
+static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t image_width, int32_t max_batch, int32_t device,
+                         bool stream_mode, dpx_handle* out) {
   if (!cfg || !out) return fail(DPX_ERR_ARG, "null argument");
   *out = nullptr;
   // plane_extractor.cpp:161-164
@@ -798,6 +812,7 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
   h->W = image_width;
   h->max_batch = max_batch;
   h->device = device;
+  h->stream_mode = stream_mode;
   // plane_extractor.cpp:155-160
   const int nh = image_width / std::max(cfg->patch_size, 1);
   const int nv = image_height / std::max(cfg->patch_size, 1);
@@ -866,7 +881,19 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
       const int Ci = static_cast<int>(C), nbi = static_cast<int>(nb);
       const dpx::R2Layout l2 = dpx::r2_layout(2, Ci, nbi, nh), l1 = dpx::r2_layout(1, Ci, nbi, nh), l0 = dpx::r2_layout(0, Ci, nbi, nh);
       // (grow_end: the grow phase's scratch behind the image, see r2_layout)
-      if (C < 65000 && std::max<size_t>(std::max<size_t>(l2.tail_end, l2.grow_end), l2.image_end + 8 * pad2) <= kLdsLimit && !want_lean && !want_gst) {
+      const bool fits2 = C < 65000 && std::max<size_t>(std::max<size_t>(l2.tail_end, l2.grow_end), l2.image_end + 8 * pad2) <= kLdsLimit;
+      const bool fits1 = C < 65000 && std::max<size_t>(l1.tail_end, l1.grow_end) <= kLdsLimit;
+      const bool fits0 = C < (size_t(1) << dpx::kKeyCellBits) && std::max<size_t>(l0.tail_end, l0.grow_end) <= kLdsLimit;
+      // Mid-size frames in stream mode (slots of a dpx_pipeline; DPX_REGIONS_GSPLIT=1 forces it for any handle): tier 0 in
+      // split form.  Its one-wave grow launch holds the flag bytes and a small scratch (28 KB for 1280x960) instead of
+      // tier 1's 9 B per cell (135 KB): five frames' grow waves per CU instead of one.  A frame's own latency is ~10 %
+      // longer (queues and seed lists in global memory), a stream of batches faster by a third and more (DESIGN.md
+      // section 5).  Taken for frames beyond tier 2 when at least two such launches fit a CU.
+      const char* gsplit = std::getenv("DPX_REGIONS_GSPLIT");
+      const bool force_split = gsplit && gsplit[0] == '1';
+      const bool split0 = fits0 && !want_gst && !want_lean && 2 * static_cast<size_t>(dpx::r2_lean_grow_end(l0, nbi)) <= kLdsLimit &&
+                          (force_split || (stream_mode && !(fits2 && !want_lean)));
+      if (fits2 && !want_lean && !want_gst && !force_split) {
         h->regions_tier = 2;
         h->sort_pad = static_cast<int>(pad2);
         h->lds2_img = l2.image_end;
@@ -875,14 +902,22 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
         h->lds2_p3 = l2.tail_end;
         h->lds2_p4 = std::max<size_t>(dpx::r2_fused_lds_bytes(l2, Ci), l2.grow_end);
         h->lds2_bytes = std::max<size_t>(std::max<size_t>(l2.tail_end, l2.grow_end), l2.image_end + 8 * pad2);
-      } else if (C < 65000 && std::max<size_t>(l1.tail_end, l1.grow_end) <= kLdsLimit && !want_gst) {
+      } else if (split0) {
+        h->regions_tier = 0;
+        h->tier0_split = true;
+        h->lds2_img = l0.image_end;
+        h->lds2_p1 = l0.image_end;
+        h->lds2_p2 = dpx::r2_lean_grow_end(l0, nbi);
+        h->lds2_p3 = l0.tail_end;
+        h->lds2_bytes = std::max<size_t>(l0.tail_end, l0.grow_end);
+      } else if (fits1 && !want_gst) {
         h->regions_tier = 1;
         h->lds2_img = l1.image_end;
         h->lds2_p1 = l1.image_end;
         h->lds2_p2 = l1.grow_end;
         h->lds2_p3 = l1.tail_end;
         h->lds2_bytes = std::max<size_t>(l1.tail_end, l1.grow_end);
-      } else if (C < (size_t(1) << dpx::kKeyCellBits) && std::max<size_t>(l0.tail_end, l0.grow_end) <= kLdsLimit) {
+      } else if (fits0) {
         h->regions_tier = 0;
         h->lds2_img = l0.image_end;
         h->lds2_bytes = std::max<size_t>(l0.tail_end, l0.grow_end);
@@ -956,9 +991,9 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
           rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
     }
   }
-  if (rc == DPX_OK && (h->regions_tier == 2 || h->regions_tier == 1)) {
+  if (rc == DPX_OK && (h->regions_tier == 2 || h->regions_tier == 1 || h->tier0_split)) {
     const char* nosplit = std::getenv("DPX_REGIONS_NOSPLIT");
-    h->regions_split = !(nosplit && nosplit[0] == '1');
+    h->regions_split = h->tier0_split || !(nosplit && nosplit[0] == '1');
     if (h->regions_split) {
       A(dev_alloc(&h->d_lds_img, B * (h->lds2_img / 16)));
       const void* fns[3];
@@ -966,10 +1001,14 @@ int dpx_create(const dpx_config* cfg, int32_t image_height, int32_t image_width,
         fns[0] = h->opt_prep_v1 ? reinterpret_cast<const void*>(dpx::k_regions2<2, false, 1>) : reinterpret_cast<const void*>(dpx::k_region_prep);
         fns[1] = reinterpret_cast<const void*>(dpx::k_regions2<2, false, 2>);
         fns[2] = reinterpret_cast<const void*>(dpx::k_regions2<2, false, 3>);
-      } else {
+      } else if (h->regions_tier == 1) {
         fns[0] = reinterpret_cast<const void*>(dpx::k_regions2<1, false, 1>);
         fns[1] = reinterpret_cast<const void*>(dpx::k_regions2<1, false, 2>);
         fns[2] = reinterpret_cast<const void*>(dpx::k_regions2<1, false, 3>);
+      } else {
+        fns[0] = reinterpret_cast<const void*>(dpx::k_regions2<0, false, 1>);
+        fns[1] = reinterpret_cast<const void*>(dpx::k_regions2<0, false, 2>);
+        fns[2] = reinterpret_cast<const void*>(dpx::k_regions2<0, false, 3>);
       }
       const size_t need[3] = {h->lds2_p1, h->lds2_p2, h->lds2_p3};
       for (int i = 0; i < 3 && rc == DPX_OK; ++i)
@@ -1355,7 +1394,7 @@ int dpx_pipeline_create(const dpx_config* cfg, int32_t image_height, int32_t ima
   p->batch = batch;
   for (int i = 0; i < slots; ++i) {
     dpx_handle h = nullptr;
-    const int rc = dpx_create(cfg, image_height, image_width, batch * group, device, &h);
+    const int rc = create_handle(cfg, image_height, image_width, batch * group, device, /*stream_mode=*/true, &h);
     if (rc != DPX_OK) {
       const std::string keep = g_err;
       dpx_pipeline_destroy(p);

@@ -100,6 +100,8 @@ __host__ __device__ constexpr int claim_bits(int) { return 12; }
 // Tier 0 keeps the BFS queue in global memory; the last 2^kRingBits entries are mirrored in an LDS ring, which is where
 // the BFS reads its batch from (a batch is at most 128 entries behind the tail unless the frontier is wider than the ring).
 constexpr int kRingBits = 13;
+// one-wave tier-0 grow launch (split form): small claim table and ring, so that several frames' grow waves share a CU
+constexpr int kLeanClaimBits = 10, kLeanRingBits = 10;
 // The BFS and the seed scan read the flag byte / queue position of a cell's four neighbours WITHOUT clamping the index
 // (an index outside the grid is masked by the in-edge bit of that non-existent neighbour): `nh` guard bytes in front
 // of and behind the flag array (and the arrays that follow it) keep every such read inside the allocation.
@@ -137,6 +139,10 @@ __host__ __device__ inline R2Layout r2_layout(int tier, int C, int nb, int nh) {
   L.grow_end = tier == 2 ? L.grow_x  // (tier 2 grows event by event: no scratch)
                          : L.grow_x + 8u * static_cast<uint32_t>(nb) + (4u << claim_bits(tier)) + (tier == 0 ? (4u << kRingBits) : 0u);
   return L;
+}
+// LDS of the one-wave tier-0 grow launch of the split form
+__host__ __device__ inline uint32_t r2_lean_grow_end(const R2Layout& L, int nb) {
+  return L.grow_x + 8u * static_cast<uint32_t>(nb) + (4u << kLeanClaimBits) + (4u << kLeanRingBits);
 }
 
 struct Regions2Extra {
@@ -187,14 +193,15 @@ template <int TIER, bool DBG, int PHASE>
 // (second launch bound: 7 workgroups of kPrepRT = 256 threads per CU = 7 waves per SIMD = at most 72 registers)
 __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE == 4 ? kPrepRT : kRT)), PHASE == 4 ? 7 : 1) void k_regions2(Params prm, RegionBufs rb, Regions2Extra rx) {
   // (inside the kernel kRT / kRW are THIS launch's workgroup size: the tail may run with fewer waves)
-  constexpr int kRT = PHASE == 3 ? dpx::kTailRT : (PHASE == 4 ? dpx::kPrepRT : dpx::kRT);
+  constexpr int kRT = PHASE == 3 ? dpx::kTailRT : (PHASE == 4 ? dpx::kPrepRT : (PHASE == 2 ? 64 : dpx::kRT));
   constexpr int kRW = kRT / 64;
   constexpr bool FULL = TIER == 2;
   constexpr bool HASBIN = TIER >= 1;  // bin of every cell in LDS (tier 0 reads the cell-graph words in global memory)
   constexpr bool GST = TIER == 0;
   using idx_t = typename std::conditional<GST, uint32_t, uint16_t>::type;
   constexpr uint32_t kNoPos = GST ? 0xFFFFFFFFu : 0xFFFFu;
-  static_assert(PHASE == 0 || TIER >= 1, "the phase-split launches need the cell labels in LDS");
+  // (tier 0 in split form: its label map and queues are in global memory anyway; the grow launch is ONE wave, so large
+  // regions are not widened over a workgroup there — the form is for streams of mid-size frames, see the host side)
   static_assert(PHASE != 4 || (TIER == 2 && !DBG), "the fused preparation + grow launch exists for tier 2");
   WaveTrace trace_(PHASE == 1 ? TK_PREP : ((PHASE == 2 || PHASE == 4) ? TK_GROW : TK_TAIL));
 #if DPX_REGIONS_PRIO
@@ -446,7 +453,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
     // per-grow barrier and join when a BFS queue gets wide (>= kWideSlots pending cells): then every wave takes 16
     // consecutive queue slots of a batch, appends in (wave, lane) order through per-wave counts, and the FIFO order
     // stays the reference's.  All control decisions are read from LDS after a barrier, so they are workgroup-uniform.
-    constexpr int kWideSlots = 64;
+    constexpr int kWideSlots = PHASE == 2 ? (1 << 30) : 64;  // (one-wave grow launch: never)
     int remaining = planar_total;
     int tail = 0, ngrow = 0, ncand = 0;
     const int nnz = hdr[5];
@@ -460,7 +467,9 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
     const int reg_sets = nsets;
     // grow-phase scratch (r2_layout): the cached seed of every bin and the claim table of a sweep round
     constexpr uint32_t kCandNone = 0xFFFFFFFFu, kCandBig = 0x80000000u;
-    constexpr int kClaimBits = claim_bits(TIER);
+    constexpr bool LEAN = GST && PHASE == 2;  // one-wave tier-0 grow launch: small scratch, several frames per CU
+    constexpr int kClaimBits = LEAN ? kLeanClaimBits : claim_bits(TIER);
+    constexpr int kRingBitsL = LEAN ? kLeanRingBits : kRingBits;
     constexpr int kSpecMax = 8;  // cells of a speculative grow: one relative cell code per byte of a 64-bit register pair
     // Rounds with fewer events take the first one on its own (see there): a sweep round costs about what four single
     // events cost, and on average 60 % of a round's events are committed before it stops.
@@ -472,7 +481,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
     uint32_t* bclaim = candc + nb;
     uint32_t* ctab = bclaim + nb;
     uint32_t* ring = ctab + (1 << kClaimBits);  // tier 0 only
-    constexpr uint32_t kRingMask = (1u << kRingBits) - 1u;
+    constexpr uint32_t kRingMask = (1u << kRingBitsL) - 1u;
     auto claim_slot = [&](uint32_t k) { return (k * 2654435761u) >> (32 - kClaimBits); };
     if (TIER != 2 && wid == 0) {
       for (int i = lane; i < nb; i += 64) {
@@ -1083,7 +1092,10 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
             const bool active = slot < nslots;
             const int qi = head + (active ? slot : 0);
             const uint32_t uh = static_cast<uint32_t>(head), us = static_cast<uint32_t>(slot);
-            const int u = GST ? static_cast<int>(ring[static_cast<uint32_t>(qi) & kRingMask]) : static_cast<int>(queue[qi]);  // (tier 0: fewer than 64 entries behind the tail here)
+            // (tier 0: the batch is in the LDS ring unless the frontier is wider than the ring — then from global memory,
+            // which the fence at the end of the previous step made visible)
+            const int u = GST ? ((tail - head) <= (1 << kRingBitsL) - 32 ? static_cast<int>(ring[static_cast<uint32_t>(qi) & kRingMask]) : static_cast<int>(queue[qi]))
+                              : static_cast<int>(queue[qi]);
             const int vraw = u + delta;
             const bool inrange = active && (vraw >= 0) && (vraw < C);
             const int v = vraw < 0 ? 0 : (vraw >= C ? C - 1 : vraw);
@@ -1152,7 +1164,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
             const bool active = gs < ns;
             const int qi = H + (active ? gs : 0);
             const uint32_t uh = static_cast<uint32_t>(H), us = static_cast<uint32_t>(gs);
-            const int u = (T - H) <= (1 << kRingBits) - 256 ? static_cast<int>(ring[static_cast<uint32_t>(qi) & kRingMask]) : static_cast<int>(queue[qi]);  // (uniform)
+            const int u = (T - H) <= (1 << kRingBitsL) - 256 ? static_cast<int>(ring[static_cast<uint32_t>(qi) & kRingMask]) : static_cast<int>(queue[qi]);  // (uniform)
             const int vraw = u + delta;
             const bool inrange = active && (vraw >= 0) && (vraw < C);
             const int v = vraw < 0 ? 0 : (vraw >= C ? C - 1 : vraw);

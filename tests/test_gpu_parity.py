@@ -245,7 +245,7 @@ def test_ragged_and_tiny_images(D, oracle):
                     del os.environ[env]
 
 
-@pytest.mark.parametrize("env", ["DPX_FORCE_GLOBAL_STATE", "DPX_REGIONS_V1", "DPX_REGIONS_LEAN", "DPX_REGIONS_GSTATE", "DPX_NO_FASTDIV", "DPX_PLANEFIT_V1", "DPX_LABELS_V1", "DPX_REGIONS_NOSPLIT", "DPX_FUSED_LABELS", "DPX_PREP_V1", "DPX_PREP_GROW_SPLIT"])
+@pytest.mark.parametrize("env", ["DPX_FORCE_GLOBAL_STATE", "DPX_REGIONS_V1", "DPX_REGIONS_LEAN", "DPX_REGIONS_GSTATE", "DPX_NO_FASTDIV", "DPX_PLANEFIT_V1", "DPX_LABELS_V1", "DPX_REGIONS_NOSPLIT", "DPX_FUSED_LABELS", "DPX_PREP_V1", "DPX_PREP_GROW_SPLIT", "DPX_REGIONS_GSPLIT"])
 def test_kernel_variants(D, oracle, env):
     """Every kernel variant must give the same bits: region growing with its per-cell state in global memory
     (used when a frame does not fit LDS), the v1 single-wave kernel, the lean LDS tier and the flag-byte-only tier (both
@@ -266,10 +266,12 @@ def test_kernel_variants(D, oracle, env):
         del os.environ[env]
 
 
-@pytest.mark.parametrize("env", [None, "DPX_CSR_CHUNK"])
+@pytest.mark.parametrize("env", [None, "DPX_CSR_CHUNK", "DPX_REGIONS_GSPLIT"])
 def test_large_frames(D, oracle, env):
     """BASELINE configs 3 and 5 in small: 1280x960 (lean LDS tier, hundreds of planes -> CSR merge walk) and one
-    3840x2160 frame (82 944 cells: flag byte in LDS, queues in global memory, 32-bit indices, thousands of grows)."""
+    3840x2160 frame (82 944 cells: flag byte in LDS, queues in global memory, 32-bit indices, thousands of grows).
+    DPX_REGIONS_GSPLIT: the 1280x960 frames through the split form of tier 0 (one-wave grow launch with a small scratch,
+    what the slots of a pipeline take for frames of this size)."""
     if env:
         os.environ[env] = "1"  # every adjacency row takes the wide (bit-row) walk
     try:
