@@ -46,9 +46,10 @@ def dist_env():
 #   4096 frames), synth4k = one GPU's share of configs[4] (3840x2160, 8 of the 64 frames).  A step is one whole batch.
 # `streams` = whole batches in flight (pipeline slots, one launch sequence each): region growing of a large frame is a
 # latency-bound sequence on one wave, so a stream of batches gains from depth until the chip-wide kernels (plane fit,
-# seed-list sort, tails, label expansion) fill the time: 1280x960 x 256: 101 k / 157 k / 197 k frames/s with 2 / 4 / 8
-# batches in flight; 3840x2160 x 8: 0.85 k / 1.6 k / 3.0 k (8 in flight = the 64 frames of configs[4] on this one GPU).
-BIG_WORKLOADS = {"synth1280": dict(batch=256, unique=8, steps=32, warmup=8, streams=8), "synth640": dict(batch=512, unique=16, steps=40, warmup=4, streams=4),
+# seed-list sort, tails, label expansion) fill the time: 1280x960 x 256: 101 k / 157 k / 199 k / 208 k / 185 k frames/s with
+# 2 / 4 / 8 / 12 / 16 batches in flight; 640x480 x 512: 0.78 M / 1.19 M / 1.48 M / 1.37 M with 2 / 4 / 8 / 16; 3840x2160 x 8:
+# 0.85 k / 1.6 k / 3.0 k with 2 / 4 / 8 (8 in flight = the 64 frames of configs[4] on this one GPU).
+BIG_WORKLOADS = {"synth1280": dict(batch=256, unique=8, steps=32, warmup=8, streams=8), "synth640": dict(batch=512, unique=16, steps=64, warmup=16, streams=8),
                  "synth4k": dict(batch=8, unique=4, steps=24, warmup=8, streams=8)}
 
 
