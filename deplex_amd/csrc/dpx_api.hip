@@ -908,6 +908,8 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
         h->lds2_img = l0.image_end;
         h->lds2_p1 = l0.image_end;
         h->lds2_p2 = dpx::r2_lean_grow_end(l0, nbi);
+        if (const char* pad = std::getenv("DPX_GROW_LDS_PAD"))  // tuning hook: KB added to the one-wave grow launch (fewer frames per CU)
+          h->lds2_p2 += static_cast<size_t>(std::max(0, std::atoi(pad))) * 1024;
         h->lds2_p3 = l0.tail_end;
         h->lds2_bytes = std::max<size_t>(l0.tail_end, l0.grow_end);
       } else if (fits1 && !want_gst) {

@@ -101,7 +101,13 @@ __host__ __device__ constexpr int claim_bits(int) { return 12; }
 // the BFS reads its batch from (a batch is at most 128 entries behind the tail unless the frontier is wider than the ring).
 constexpr int kRingBits = 13;
 // one-wave tier-0 grow launch (split form): small claim table and ring, so that several frames' grow waves share a CU
-constexpr int kLeanClaimBits = 10, kLeanRingBits = 10;
+#ifndef DPX_LEAN_CLAIM_BITS
+#define DPX_LEAN_CLAIM_BITS 10
+#endif
+#ifndef DPX_LEAN_RING_BITS
+#define DPX_LEAN_RING_BITS 10
+#endif
+constexpr int kLeanClaimBits = DPX_LEAN_CLAIM_BITS, kLeanRingBits = DPX_LEAN_RING_BITS;
 // The BFS and the seed scan read the flag byte / queue position of a cell's four neighbours WITHOUT clamping the index
 // (an index outside the grid is masked by the in-edge bit of that non-existent neighbour): `nh` guard bytes in front
 // of and behind the flag array (and the arrays that follow it) keep every such read inside the allocation.
