@@ -14,6 +14,12 @@
 //     (LDS atomic) and the arg-max runs over a register-resident list of the non-empty bins;
 //   * seeds whose neighbours cannot be activated are committed without a BFS step; in tier 0 large regions grow with
 //     workgroup-wide BFS batches;
+//   * large frames (tiers 1 and 0) do not take one grow after the other: the bins that stand at the histogram's maximum
+//     fire in ascending order and do not influence each other unless their grows touch, so up to 64 of them are grown
+//     speculatively at once, one lane each, checked against each other with claim tables and committed together
+//     ("sweep rounds", see the comment in the grow phase: 18 776 grows of a noisy 3840x2160 frame in ~4 100 rounds);
+//   * tier 0 also exists as three launches with a ONE-wave grow launch that keeps 28 KB of LDS for a 1280x960 frame:
+//     what the slots of a pipeline take, because then five frames' grow waves share a CU;
 //   * wave reductions use DPP row shifts / broadcasts (gfx9) instead of ds_bpermute butterflies;
 //   * the parallel phases (state load, sort, float accumulation of the grown segments, f64 segment fits, label
 //     writes, adjacency build) use all eight waves; the inherently sequential sequence of grows runs on wave 0 — as a
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
   unsigned long long t_start = DPX_STAMP(), t_p0 = 0, t_p1 = 0, t_p2 = 0, t_p3 = 0, t_p4 = 0, t_p5 = 0;
   const unsigned long long t_res = (PHASE > 0 && rx.res) ? static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) : 0ull;
   const unsigned long long t_real = ((PHASE == 2 || PHASE == 4) && rx.res) ? static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()) : 0ull;
-  unsigned long long a_argmax = 0, a_seed = 0, a_bfs = 0, a_rem = 0, n_steps = 0, n_spec = 0, n_rounds = 0, n_scan1 = 0, n_scan64 = 0, a_scan = 0, a_spec = 0, n_pops = 0, n_stop_inc = 0, n_stop_bin = 0, n_stop_cell = 0, a_claims = 0, a_commit = 0, n_fast = 0, a_fast = 0;
+  unsigned long long a_argmax = 0, a_seed = 0, a_bfs = 0, n_steps = 0, n_spec = 0, n_rounds = 0, n_scan1 = 0, n_scan64 = 0, a_scan = 0, a_spec = 0, n_pops = 0, n_stop_inc = 0, n_stop_bin = 0, n_stop_cell = 0, a_claims = 0, a_commit = 0, n_fast = 0, a_fast = 0;
   const int frame = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int C = prm.C, nh = prm.nh, nv = prm.nv;
@@ -521,8 +527,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
       ++ngrow;
       remaining -= g;
       if (DBG) {
-        const unsigned long long te = DPX_STAMP();
-        a_argmax += tb - ta; a_seed += tc - tb; a_bfs += td - tc; a_rem += te - td;
+        a_argmax += tb - ta; a_seed += tc - tb; a_bfs += td - tc;
       }
     };
     for (int round = 0;; ++round) {
