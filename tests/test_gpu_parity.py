@@ -614,6 +614,27 @@ def test_pipeline_group_with_mixed_intrinsics(D, oracle):
             del view
 
 
+def test_pipeline_submit_many_equals_single_submits(D, oracle):
+    """dpx_pipeline_submit_depth_many: n submissions in one call keep the order and grouping of n single calls."""
+    import torch
+    depth = synth.synth_batch(4, 240, 320, seed0=90)
+    intr = synth.intrinsics_for(240, 320)
+    dev = torch.device("cuda", 0)
+    ins = [torch.from_numpy(np.roll(depth, k, axis=0).copy().view(np.int16)).to(dev) for k in range(7)]
+    oracle.set_math("devmath")
+    ref = oracle.process_depth_batch(oracle.default_config(), depth, *intr)
+    outs = [torch.full((4, 240 * 320), -1, dtype=torch.int32, device=dev) for _ in range(7)]
+    pipe = D.Pipeline(240, 320, D.Config(), batch=4, slots=2, group=3)
+    pipe.submit_depth_many([t.data_ptr() for t in ins[:5]], 4, *intr, [t.data_ptr() for t in outs[:5]])
+    pipe.submit_depth(ins[5].data_ptr(), 4, *intr, outs[5].data_ptr())
+    pipe.submit_depth_many([ins[6].data_ptr()], 4, *intr, [outs[6].data_ptr()])
+    pipe.sync()
+    for k in range(7):
+        assert np.array_equal(outs[k].cpu().numpy(), np.roll(ref, k, axis=0)), k
+    with pytest.raises(ValueError):
+        pipe.submit_depth_many([ins[0].data_ptr()], 4, *intr, [])
+
+
 def test_pipeline_group_of_many_submissions(D, oracle):
     """A group holds up to 32 submissions (the per-submission tables of the group launches are kernel arguments): 11
     single-frame submissions with alternating intrinsics in groups of 11 and of 32 (flushed partly filled by sync),
