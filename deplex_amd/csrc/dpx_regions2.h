@@ -1402,6 +1402,11 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
   }
   const int pv_room = GST ? (pv_off < lay.flags + static_cast<uint32_t>(C) ? static_cast<int>(lay.flags + C - pv_off) : 0) : 4 * C;
   const bool fast = nplanes * 32 <= pv_room && nplanes * wpr <= kMatWords;
+  // Larger plane counts (CSR walk below): the 7-float views and the merge labels still go to LDS when they fit — the
+  // walk then reads a row's and its columns' parameters from LDS instead of gathering plane records from global memory,
+  // four dependent round trips per row less (1 716 planes on a noisy 4K frame: 48 KB of the dead flag array).  In the
+  // LDS tiers the bit row of the wide-row walk follows the views.
+  const bool views = nplanes > 0 && !fast && nplanes * 32 + (GST ? 0 : wpr * 4) <= pv_room;
   // The merge walk below is one wave's work, and so is what follows it for a frame of a few thousand cells: when the
   // walk does not need the workgroup (no CSR build, no fused label expansion), waves 1.. end here and give their
   // registers and wave slots back to the chip; wave 0 finishes the frame alone, without further workgroup barriers.
@@ -1573,9 +1578,19 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
       if (hl >= 0) cols[off[hl] + atomicAdd(&cnt[hl], 1u)] = static_cast<uint32_t>(hh);
       if (vl >= 0) cols[off[vl] + atomicAdd(&cnt[vl], 1u)] = static_cast<uint32_t>(vh);
     }
+    if (views)
+      for (int i = tid; i < nplanes; i += kRT) {
+        const dpx_plane& pl = planes[i];
+        float* pv = pview + i * 7;
+        pv[0] = pl.normal[0]; pv[1] = pl.normal[1]; pv[2] = pl.normal[2]; pv[3] = pl.d;
+        pv[4] = pl.mean[0]; pv[5] = pl.mean[1]; pv[6] = pl.mean[2];
+        lmerge[i] = i;
+      }
     __syncthreads();
     if (wid == 0) {
-      uint32_t* slowbits = reinterpret_cast<uint32_t*>(qpos);  // bit row for planes with more than 64 adjacency entries
+      // bit row for planes with more than 64 adjacency entries (tier 0: global scratch; LDS tiers: behind the views, or
+      // the dead queue-position array when there are none)
+      uint32_t* slowbits = (views && !GST) ? reinterpret_cast<uint32_t*>(lmerge + nplanes) : reinterpret_cast<uint32_t*>(qpos);
       for (int rbase = 0; rbase < nplanes; rbase += 64) {
         const int rr = rbase + lane;
         const uint32_t o0 = rr < nplanes ? off[rr] : 0u, o1 = rr < nplanes ? off[rr + 1] : 0u;
@@ -1586,26 +1601,41 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
           const int row = rbase + rl;
           const int s0 = __builtin_amdgcn_readlane(static_cast<int>(o0), rl), e0 = __builtin_amdgcn_readlane(static_cast<int>(o1), rl);
           const int deg = e0 - s0;
-          const int pid = merge[row];
-          const dpx_plane& pp_ = planes[pid];
-          const float pnx = pp_.normal[0], pny = pp_.normal[1], pnz = pp_.normal[2], pd = pp_.d;
+          const int pid = views ? lmerge[row] : merge[row];
+          float pnx, pny, pnz, pd;
+          if (views) {
+            const float* pv = pview + pid * 7;
+            pnx = pv[0]; pny = pv[1]; pnz = pv[2]; pd = pv[3];
+          } else {
+            const dpx_plane& pp_ = planes[pid];
+            pnx = pp_.normal[0]; pny = pp_.normal[1]; pnz = pp_.normal[2]; pd = pp_.d;
+          }
+          // a column plane's normal and mean for the merge test
+          auto col_test = [&](uint32_t col) {
+            if (views) {
+              const float* cv = pview + col * 7;
+              return merge_test(pnx, pny, pnz, pd, cv[0], cv[1], cv[2], cv[4], cv[5], cv[6]);
+            }
+            const dpx_plane& pc = planes[col];
+            return merge_test(pnx, pny, pnz, pd, pc.normal[0], pc.normal[1], pc.normal[2], pc.mean[0], pc.mean[1], pc.mean[2]);
+          };
           bool expanded = false;
           auto fold = [&](int colx) {  // plane_extractor.cpp:413-417: accumulate the column's sums into the row's plane
             float* pf = reinterpret_cast<float*>(&planes[pid]);
             const float* cfp = reinterpret_cast<const float*>(&planes[colx]);
             if (lane < 9) pf[lane] = pf[lane] + cfp[lane];
             if (lane == 9) planes[pid].n_pts += planes[colx].n_pts;
-            if (lane == 10) merge[colx] = pid;
+            if (lane == 10) {
+              merge[colx] = pid;
+              if (views) lmerge[colx] = pid;
+            }
             expanded = true;
             ++merges;
           };
           if (deg <= rx.csr_chunk) {
             const uint32_t col = lane < deg ? cols[s0 + lane] : 0xFFFFFFFFu;
             bool acc = false;
-            if (lane < deg) {
-              const dpx_plane& pc = planes[col];
-              acc = merge_test(pnx, pny, pnz, pd, pc.normal[0], pc.normal[1], pc.normal[2], pc.mean[0], pc.mean[1], pc.mean[2]);
-            }
+            if (lane < deg) acc = col_test(col);
             // accepted columns in ascending order; duplicates of a column are retired together
             while (__ballot(acc)) {
               const uint32_t cmin = wave_min_u32(acc ? col : 0xFFFFFFFFu);
@@ -1624,10 +1654,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
             for (int cbase = row + 1; cbase < nplanes; cbase += 64) {
               const int col = cbase + lane;
               bool acc = false;
-              if (col < nplanes && ((slowbits[col >> 5] >> (col & 31)) & 1u)) {
-                const dpx_plane& pc = planes[col];
-                acc = merge_test(pnx, pny, pnz, pd, pc.normal[0], pc.normal[1], pc.normal[2], pc.mean[0], pc.mean[1], pc.mean[2]);
-              }
+              if (col < nplanes && ((slowbits[col >> 5] >> (col & 31)) & 1u)) acc = col_test(static_cast<uint32_t>(col));
               unsigned long long mask = __ballot(acc);
               while (mask) {
                 const int l = __builtin_ctzll(mask);
@@ -1646,6 +1673,11 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
               pl.mean[0] = fit.mean[0]; pl.mean[1] = fit.mean[1]; pl.mean[2] = fit.mean[2];
               pl.normal[0] = fit.normal[0]; pl.normal[1] = fit.normal[1]; pl.normal[2] = fit.normal[2];
               pl.d = fit.d; pl.mse = fit.mse; pl.score = fit.score;
+              if (views) {
+                float* pw = pview + pid * 7;
+                pw[0] = fit.normal[0]; pw[1] = fit.normal[1]; pw[2] = fit.normal[2]; pw[3] = fit.d;
+                pw[4] = fit.mean[0]; pw[5] = fit.mean[1]; pw[6] = fit.mean[2];
+              }
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -1660,7 +1692,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
   // ---------------- P6: merged label per cell (toImageLabels' lookup, plane_extractor.cpp:464-465); records --------
   // (merge labels from their LDS copy where the merge ran on the bit matrix: one wave walks all cells here, and a
   // global gather per iteration would be a serialized memory round trip each)
-  const bool lds_merge = nplanes > 0 && fast;
+  const bool lds_merge = nplanes > 0 && (fast || views);
   for (int c = tid; c < C; c += tstride) {
     const int L = lab16[c];
     const int fin = (L == 0 || nplanes == 0) ? 0 : (lds_merge ? lmerge[L - 1] : merge[L - 1]) + 1;
