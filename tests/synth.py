@@ -76,6 +76,40 @@ def synth_depth(h: int, w: int, seed: int = 0, noise: bool = True, dropout: bool
     return np.clip(np.rint(z), 0, 65535).astype(np.uint16)
 
 
+def quilt_depth(h: int, w: int, seed: int = 0, P: int = 10, kmax: int = 3, ntilt: int = 6, jitter: float = 0.0, drop: float = 0.05) -> np.ndarray:
+    """A quilt of small planar patches (1..kmax cells of P pixels on a side) whose tilts come from a handful of directions
+    and whose depths partly coincide: many histogram bins hold the same number of cells, most grows are a few cells next
+    to other small grows, and some span patches.  The worst case for the sweep rounds of the region kernel (many events
+    per histogram level, grows that touch, bins that lose cells in the middle of a sweep): 2 600 - 22 500 grows and
+    1 100 - 7 700 plane segments per frame where the piecewise-planar rooms of synth_depth have a few hundred."""
+    rng = np.random.default_rng(0x9E3779B97F4A7C15 ^ int(seed))
+    fx, fy, cx, cy = intrinsics_for(h, w)
+    nh, nv = w // P, h // P
+    tilts = []
+    for _ in range(ntilt):
+        t, a = np.deg2rad(rng.uniform(5, 55)), rng.uniform(0, 2 * np.pi)
+        tilts.append((np.tan(t) * np.cos(a), np.tan(t) * np.sin(a)))
+    z = np.zeros((h, w))
+    yy, xx = np.mgrid[0:h, 0:w]
+    r = 0
+    while r < nv:
+        kh = int(rng.integers(1, kmax + 1))
+        c = 0
+        while c < nh:
+            kw = int(rng.integers(1, kmax + 1))
+            gx, gy = tilts[int(rng.integers(0, ntilt))]
+            z0 = rng.uniform(1500, 4000) if rng.random() < 0.5 else 2500 + 40 * ((r + c) % 5)
+            ys, xs = slice(r * P, min((r + kh) * P, h)), slice(c * P, min((c + kw) * P, w))
+            z[ys, xs] = z0 * (1 + gx * (xx[ys, xs] - c * P) / fx + gy * (yy[ys, xs] - r * P) / fy)
+            c += kw
+        r += kh
+    if jitter:
+        z += rng.standard_normal(z.shape) * jitter
+    dropm = rng.random((nv + 1, nh + 1)) < drop
+    z[np.repeat(np.repeat(dropm, P, 0), P, 1)[:h, :w]] = 0
+    return np.clip(np.rint(z), 0, 65535).astype(np.uint16)
+
+
 def synth_batch(batch: int, h: int, w: int, seed0: int = 0, **kw) -> np.ndarray:
     return np.stack([synth_depth(h, w, seed=seed0 + i, **kw) for i in range(batch)])
 

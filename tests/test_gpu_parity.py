@@ -375,6 +375,28 @@ def test_sweep_rounds_corner_configs(D, oracle, h, w, seed, ov):
     full_compare(D, oracle, depth, synth.intrinsics_for(h, w), oracle.default_config(**ov))
 
 
+@pytest.mark.parametrize("env", [None, "DPX_REGIONS_GSPLIT", "DPX_REGIONS_GSTATE"])
+def test_sweep_rounds_quilt_scenes(D, oracle, env):
+    """Quilts of small planar patches (synth.quilt_depth): thousands of small grows next to each other, many bins at the
+    same histogram level — the sweep rounds' claim tables, skips and stops under the heaviest load the generators can
+    produce; tier 1, the split and the single-launch form of tier 0, and a 4K frame (22 000 grows, 7 700 segments)."""
+    if env:
+        os.environ[env] = "1"
+    try:
+        depth = np.stack([synth.quilt_depth(960, 1280, seed=1), synth.quilt_depth(960, 1280, seed=2, kmax=2, ntilt=3),
+                          synth.quilt_depth(960, 1280, seed=5, kmax=4, ntilt=12, jitter=0.4)])
+        full_compare(D, oracle, depth, synth.intrinsics_for(960, 1280), oracle.default_config())
+        full_compare(D, oracle, depth[:2], synth.intrinsics_for(960, 1280), oracle.default_config(min_region_growing_cells_activated=2, min_cos_angle_merge=0.8))
+        if env is None:
+            big = synth.quilt_depth(2160, 3840, seed=3, kmax=3, ntilt=8, jitter=0.3)[None]
+            full_compare(D, oracle, big, synth.intrinsics_for(2160, 3840), oracle.default_config())
+            mid = np.stack([synth.quilt_depth(1080, 1920, seed=s, kmax=2, ntilt=4) for s in (7, 8)])
+            full_compare(D, oracle, mid, synth.intrinsics_for(1080, 1920), oracle.default_config(patch_size=8))
+    finally:
+        if env:
+            del os.environ[env]
+
+
 def test_fast_division_is_verified(D):
     """The reciprocal division of the fast plane-fit kernel is accepted only after an exhaustive device-side check
     against IEEE division for the frame geometry; the fixtures' intrinsics (including ICL's negative fy) pass it."""

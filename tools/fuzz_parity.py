@@ -75,7 +75,12 @@ for it in range(cases):
     B = int(rng.integers(1, 4))
     seed = int(rng.integers(0, 10000))
     kw = dict(noise=bool(rng.random() < 0.8), dropout=bool(rng.random() < 0.8), scale=float(rng.choice([1.0, 5.0])))
-    depth = np.stack([synth.synth_depth(h, w, seed=seed + k, **kw) for k in range(B)])
+    if rng.random() < 0.2:  # quilts of small patches: thousands of small grows next to each other (sweep rounds under load)
+        qk = dict(P=P, kmax=int(rng.integers(1, 5)), ntilt=int(rng.integers(2, 13)), jitter=float(rng.choice([0.0, 0.3, 1.0])), drop=float(rng.choice([0.0, 0.05, 0.2])))
+        depth = np.stack([synth.quilt_depth(h, w, seed=seed + k, **qk) for k in range(B)])
+        kw = qk
+    else:
+        depth = np.stack([synth.synth_depth(h, w, seed=seed + k, **kw) for k in range(B)])
     if env:
         os.environ[env] = "1"
     try:
