@@ -1367,6 +1367,7 @@ struct dpx_pipeline_s {
   std::vector<dpx_handle> slots;
   std::vector<std::vector<SubBatch>> pending;  // per slot: submissions recorded, not launched yet
   std::vector<char> pending_depth;             // per slot: input form of the pending submissions (1 depth, 0 cloud)
+  std::vector<char> pending_cells;             // per slot: output form (1 = cell labels into the submissions' buffers, 0 = pixel label maps)
   int group = 1, batch = 0;
   long long submitted = 0;
   int device = 0;
@@ -1378,7 +1379,17 @@ int pipeline_flush(dpx_pipeline p, size_t k) {
   dpx_handle h = p->slots[k];
   const int nsub = static_cast<int>(p->pending[k].size());
   int rc = stage_fit(h, p->pending[k].data(), nsub, p->batch, p->pending_depth[k] != 0, h->stream);
+  const bool cells = p->pending_cells[k] != 0;
+  if (cells) h->no_pixel_labels = true;  // cell-level submissions: no label expansion launch, the merged cell labels are copied out
   if (rc == DPX_OK) rc = stage_rest(h, p->pending[k].data(), nsub, p->batch, p->pending_depth[k] != 0, h->stream);
+  h->no_pixel_labels = false;
+  if (rc == DPX_OK && cells) {
+    const size_t per = static_cast<size_t>(p->batch) * h->prm.C;
+    for (int j = 0; j < nsub && rc == DPX_OK; ++j)
+      if (hipMemcpyAsync(p->pending[k][j].d_labels, h->d_cell_labels + static_cast<size_t>(j) * per, per * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                         h->stream) != hipSuccess)
+        rc = fail(DPX_ERR_HIP, "hipMemcpyAsync (cell labels) failed");
+  }
   p->pending[k].clear();
   return rc;
 }
@@ -1407,6 +1418,7 @@ int dpx_pipeline_create(const dpx_config* cfg, int32_t image_height, int32_t ima
   }
   p->pending.resize(p->slots.size());
   p->pending_depth.assign(p->slots.size(), 1);
+  p->pending_cells.assign(p->slots.size(), 0);
   // HIP binds a stream to a hardware queue at its first use: do that here, once, for every slot, instead of inside the
   // first groups a caller submits
   for (auto h : p->slots) (void)hipMemsetAsync(h->d_stats, 0, sizeof(dpx_frame_stats), h->stream);
@@ -1424,13 +1436,17 @@ void dpx_pipeline_destroy(dpx_pipeline p) {
 }
 
 namespace {
-int pipeline_submit(dpx_pipeline p, const void* d_in, bool depth, int32_t batch, float fx, float fy, float cx, float cy, void* d_labels) {
+int pipeline_submit(dpx_pipeline p, const void* d_in, bool depth, int32_t batch, float fx, float fy, float cx, float cy, void* d_labels,
+                    bool cells = false) {
   if (!p || !d_in || !d_labels) return fail(DPX_ERR_ARG, "bad argument");
+  if (cells && !p->slots.empty() && p->slots[0]->cfg.ransac_refinement)
+    return fail(DPX_ERR_ARG, "cell-level output is not defined with ransac_refinement (it edits single pixels)");
   if (batch != p->batch) return fail(DPX_ERR_ARG, "pipeline submissions must have the batch size given at creation");
   long long n = p->submitted;
   size_t k = static_cast<size_t>((n / p->group) % static_cast<long long>(p->slots.size()));
-  if (!p->pending[k].empty() && (p->pending_depth[k] != 0) != depth) {
-    // a group holds one input form (the refinement re-reads the input): close the open group and start a new one
+  if (!p->pending[k].empty() && ((p->pending_depth[k] != 0) != depth || (p->pending_cells[k] != 0) != cells)) {
+    // a group holds one input form (the refinement re-reads the input) and one output form: close the open group and
+    // start a new one
     const int rcf = pipeline_flush(p, k);
     if (rcf) return rcf;
     p->submitted = ((p->submitted + p->group - 1) / p->group) * p->group;
@@ -1446,6 +1462,7 @@ int pipeline_submit(dpx_pipeline p, const void* d_in, bool depth, int32_t batch,
   if (rc) return rc;
   ++p->submitted;
   p->pending_depth[k] = depth ? 1 : 0;
+  p->pending_cells[k] = cells ? 1 : 0;
   p->pending[k].push_back(sb);
   if (j == p->group - 1) rc = pipeline_flush(p, k);
   return rc;
@@ -1455,6 +1472,11 @@ int pipeline_submit(dpx_pipeline p, const void* d_in, bool depth, int32_t batch,
 int dpx_pipeline_submit_depth(dpx_pipeline p, const void* d_depth, int32_t batch, float fx, float fy, float cx, float cy,
                               void* d_labels) {
   return pipeline_submit(p, d_depth, true, batch, fx, fy, cx, cy, d_labels);
+}
+
+int dpx_pipeline_submit_depth_cells(dpx_pipeline p, const void* d_depth, int32_t batch, float fx, float fy, float cx, float cy,
+                                    void* d_cell_labels) {
+  return pipeline_submit(p, d_depth, true, batch, fx, fy, cx, cy, d_cell_labels, /*cells=*/true);
 }
 
 int dpx_pipeline_submit_depth_many(dpx_pipeline p, int32_t n, const void* const* d_depth, int32_t batch, float fx, float fy, float cx,

@@ -286,6 +286,11 @@ class Pipeline:
     def submit_depth(self, d_depth_ptr: int, batch: int, fx, fy, cx, cy, d_labels_ptr: int) -> None:
         _capi.check(_capi.lib().dpx_pipeline_submit_depth(self._p, d_depth_ptr, batch, fx, fy, cx, cy, d_labels_ptr))
 
+    def submit_depth_cells(self, d_depth_ptr: int, batch: int, fx, fy, cx, cy, d_cell_labels_ptr: int) -> None:
+        """Cell-level output: int32 [batch][nv][nh] merged cell labels into device memory, no pixel label map (no label
+        expansion launch for the group)."""
+        _capi.check(_capi.lib().dpx_pipeline_submit_depth_cells(self._p, d_depth_ptr, batch, fx, fy, cx, cy, d_cell_labels_ptr))
+
     def submit_depth_many(self, d_depth_ptrs, batch: int, fx, fy, cx, cy, d_labels_ptrs) -> None:
         """len(d_depth_ptrs) submissions in one call (dpx_pipeline_submit_depth_many): same order and grouping as single calls."""
         n = len(d_depth_ptrs)

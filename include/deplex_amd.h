@@ -179,6 +179,13 @@ int dpx_pipeline_create(const dpx_config* cfg, int32_t image_height, int32_t ima
 void dpx_pipeline_destroy(dpx_pipeline p);
 int dpx_pipeline_submit_depth(dpx_pipeline p, const void* d_depth, int32_t batch, float fx, float fy, float cx, float cy,
                               void* d_labels);
+/* A submission with CELL-LEVEL output (see dpx_process_depth_batch_cells): d_cell_labels receives batch x nv x nh int32
+ * (device memory), the merged 1-based label of every cell; the label expansion launch — a quarter of the pipeline's GPU
+ * time and two thirds of its HBM writes — is left out for the group.  A group holds one output form: switching forms
+ * closes the open group first.  The plane records of a slot's last group are read with dpx_get_planes on
+ * dpx_pipeline_slot() after dpx_pipeline_sync().  DPX_ERR_ARG with ransac_refinement. */
+int dpx_pipeline_submit_depth_cells(dpx_pipeline p, const void* d_depth, int32_t batch, float fx, float fy, float cx, float cy,
+                                    void* d_cell_labels);
 /* n submissions in one call (same batch size and intrinsics, one input and one output buffer each): what a caller that
  * already holds several batches does instead of n calls — the order and the grouping are those of n single calls. */
 int dpx_pipeline_submit_depth_many(dpx_pipeline p, int32_t n, const void* const* d_depth, int32_t batch, float fx, float fy,

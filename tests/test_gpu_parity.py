@@ -657,6 +657,34 @@ def test_pipeline_submit_many_equals_single_submits(D, oracle):
         pipe.submit_depth_many([ins[0].data_ptr()], 4, *intr, [])
 
 
+def test_pipeline_cell_level_submissions(D, oracle):
+    """dpx_pipeline_submit_depth_cells: cell labels of streamed batches equal the single-call cell labels (and, expanded on
+    the host, the oracle's pixel maps); pixel-map and cell-level submissions alternate in one pipeline (a group holds one
+    output form); refused with ransac_refinement."""
+    import torch
+    depth = synth.synth_batch(3, 240, 320, seed0=120)
+    intr = synth.intrinsics_for(240, 320)
+    dev = torch.device("cuda", 0)
+    oracle.set_math("devmath")
+    ref = oracle.process_depth_batch(oracle.default_config(), depth, *intr)
+    ex = D.PlaneExtractor(240, 320, max_batch=3)
+    cl_ref, _ = ex.process_depth_batch_cells(depth, *intr, planes=False)
+    assert np.array_equal(ex.expand_cell_labels(cl_ref), ref)
+    d_in = torch.from_numpy(depth.view(np.int16)).to(dev)
+    pipe = D.Pipeline(240, 320, D.Config(), batch=3, slots=2, group=2)
+    kinds = [True, True, False, True, False, False, True]  # True = cell level
+    outs = [torch.full((3, 24, 32) if c else (3, 240 * 320), -1, dtype=torch.int32, device=dev) for c in kinds]
+    for c, o in zip(kinds, outs):
+        (pipe.submit_depth_cells if c else pipe.submit_depth)(d_in.data_ptr(), 3, *intr, o.data_ptr())
+    pipe.sync()
+    for c, o in zip(kinds, outs):
+        assert np.array_equal(o.cpu().numpy(), cl_ref if c else ref)
+    cfg = D.Config()
+    cfg.ransac_refinement = True
+    with pytest.raises(D.DeplexError):
+        D.Pipeline(240, 320, cfg, batch=3, slots=1, group=1).submit_depth_cells(d_in.data_ptr(), 3, *intr, outs[0].data_ptr())
+
+
 def test_pipeline_group_of_many_submissions(D, oracle):
     """A group holds up to 32 submissions (the per-submission tables of the group launches are kernel arguments): 11
     single-frame submissions with alternating intrinsics in groups of 11 and of 32 (flushed partly filled by sync),
