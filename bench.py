@@ -49,8 +49,10 @@ def dist_env():
 # seed-list sort, tails, label expansion) fill the time: 1280x960 x 256: 101 k / 157 k / 199 k / 208 k / 185 k frames/s with
 # 2 / 4 / 8 / 12 / 16 batches in flight; 640x480 x 512: 0.78 M / 1.19 M / 1.48 M / 1.37 M with 2 / 4 / 8 / 16; 3840x2160 x 8:
 # 0.85 k / 1.6 k / 3.0 k with 2 / 4 / 8 (8 in flight = the 64 frames of configs[4] on this one GPU).
+# synth4k64 = ALL 64 frames of configs[4] per step on one GPU (the noisiest frame of a batch sets the batch's time and a frame
+# holds one CU: 64-frame batches keep 256+ frames in flight): 5.8 k / 10.0 k / 12.8 k frames/s with 2 / 4 / 8 batches in flight.
 BIG_WORKLOADS = {"synth1280": dict(batch=256, unique=8, steps=32, warmup=8, streams=8), "synth640": dict(batch=512, unique=16, steps=64, warmup=16, streams=8),
-                 "synth4k": dict(batch=8, unique=4, steps=24, warmup=8, streams=8)}
+                 "synth4k": dict(batch=8, unique=4, steps=24, warmup=8, streams=8), "synth4k64": dict(batch=64, unique=4, steps=24, warmup=8, streams=8)}
 
 
 def make_workload(name: str, batch: int, rank: int, part: int = 0, parts: int = 1, unique: int = 0):
@@ -60,7 +62,7 @@ def make_workload(name: str, batch: int, rank: int, part: int = 0, parts: int = 
     import synth
     seed0 = (rank * parts + part) * batch
     if unique and name.startswith("synth") and batch % unique == 0 and unique < batch:
-        w, h = {"synth640": (640, 480), "synth1280": (1280, 960), "synth4k": (3840, 2160)}[name]
+        w, h = {"synth640": (640, 480), "synth1280": (1280, 960), "synth4k": (3840, 2160), "synth4k64": (3840, 2160)}[name]
         uniq = synth.synth_batch(unique, h, w, seed0=seed0)
         return (np.concatenate([uniq] * (batch // unique)), synth.intrinsics_for(h, w),
                 f"synthetic {w}x{h} piecewise-planar depth, batch={batch} ({unique} distinct frames, tiled)")
@@ -70,7 +72,7 @@ def make_workload(name: str, batch: int, rank: int, part: int = 0, parts: int = 
         intr = tuple(float(v) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2]))
         return depth, intr, f"TUM fr3 640x480 depth stream (reference frame + seeded variants), batch={batch}"
     if name.startswith("synth"):
-        w, h = {"synth640": (640, 480), "synth1280": (1280, 960), "synth4k": (3840, 2160)}[name]
+        w, h = {"synth640": (640, 480), "synth1280": (1280, 960), "synth4k": (3840, 2160), "synth4k64": (3840, 2160)}[name]
         depth = synth.synth_batch(batch, h, w, seed0=seed0)
         return depth, synth.intrinsics_for(h, w), f"synthetic {w}x{h} piecewise-planar depth, batch={batch}"
     raise SystemExit(f"unknown workload {name}")

@@ -106,6 +106,8 @@ __host__ __device__ constexpr int claim_bits(int) { return 12; }
 // Tier 0 keeps the BFS queue in global memory; the last 2^kRingBits entries are mirrored in an LDS ring, which is where
 // the BFS reads its batch from (a batch is at most 128 entries behind the tail unless the frontier is wider than the ring).
 constexpr int kRingBits = 13;
+// the bins of a sweep round's events when they come from several 64-bin chunks (64 x uint16, behind the claim table)
+constexpr uint32_t kEvBytes = 128;
 // one-wave tier-0 grow launch (split form): small claim table and ring, so that several frames' grow waves share a CU
 #ifndef DPX_LEAN_CLAIM_BITS
 #define DPX_LEAN_CLAIM_BITS 10
@@ -149,12 +151,12 @@ __host__ __device__ inline R2Layout r2_layout(int tier, int C, int nb, int nh) {
   }
   L.grow_x = L.image_end;
   L.grow_end = tier == 2 ? L.grow_x  // (tier 2 grows event by event: no scratch)
-                         : L.grow_x + 8u * static_cast<uint32_t>(nb) + (4u << claim_bits(tier)) + (tier == 0 ? (4u << kRingBits) : 0u);
+                         : L.grow_x + 8u * static_cast<uint32_t>(nb) + (4u << claim_bits(tier)) + kEvBytes + (tier == 0 ? (4u << kRingBits) : 0u);
   return L;
 }
 // LDS of the one-wave tier-0 grow launch of the split form
 __host__ __device__ inline uint32_t r2_lean_grow_end(const R2Layout& L, int nb) {
-  return L.grow_x + 8u * static_cast<uint32_t>(nb) + (4u << kLeanClaimBits) + (4u << kLeanRingBits);
+  return L.grow_x + 8u * static_cast<uint32_t>(nb) + (4u << kLeanClaimBits) + kEvBytes + (4u << kLeanRingBits);
 }
 
 struct Regions2Extra {
@@ -492,7 +494,8 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
     uint32_t* candc = reinterpret_cast<uint32_t*>(smem + lay.grow_x);
     uint32_t* bclaim = candc + nb;
     uint32_t* ctab = bclaim + nb;
-    uint32_t* ring = ctab + (1 << kClaimBits);  // tier 0 only
+    uint16_t* evb = reinterpret_cast<uint16_t*>(ctab + (1 << kClaimBits));
+    uint32_t* ring = ctab + (1 << kClaimBits) + (kEvBytes >> 2);  // tier 0 only
     constexpr uint32_t kRingMask = (1u << kRingBitsL) - 1u;
     auto claim_slot = [&](uint32_t k) { return (k * 2654435761u) >> (32 - kClaimBits); };
     if (TIER != 2 && wid == 0) {
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
           // and its grow is the grow computed on the mask as of the start of the sweep unless an earlier grow of the sweep
           // activated one of its cells (growSeed's accept test reads only static per-cell data besides the unassigned
           // mask, so removing cells OUTSIDE a grow's result changes neither the result nor its order).
-          // Hence a round: up to 64 bins at level L (one chunk of the ascending list of non-empty bins), one lane each.
+          // Hence a round: the first (up to) 64 bins at level L in ascending order, one lane each.
           // Every lane grows its seed on the current mask by itself, up to kSpecMax cells (on noisy large frames two thirds
           // of all grows are a single cell and 98 % have fewer than 16); all cells and the bins of the non-seed cells are
           // claimed in a small hash table with atomic min(lane).  Lane t is CLEAN if its grow is complete, no lower lane
@@ -682,7 +685,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
                 const int t = lane + 64 * qc;
                 if (__ballot(t < nnz && hist[nzlist[t]] == bv)) break;
               }
-            // 2. the events of this round: bins of chunk qc at level bv, ascending = lane order
+            // 2. the events of this round: bins at level bv, ascending = lane order; those of chunk qc first
             int b;
             bool part;
             if (qc < 4) {
@@ -700,10 +703,47 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
               b = t < nnz ? static_cast<int>(nzlist[t]) : -1;
               part = b >= 0 && hist[b >= 0 ? b : 0] == bv;
             }
+            unsigned long long partmask = __ballot(part);
+            int nev = static_cast<int>(__popcll(partmask));
+            // The sweep does not end with the chunk: the bins at level bv of the LATER chunks fire right after these, in the
+            // same ascending order.  They are appended (through a 64-entry staging array: event e = lane e) until the round
+            // is full — a frame with 300 non-empty bins spreads the 20 events of a typical sweep over five chunks, which
+            // would otherwise be five rounds of four events, i.e. twenty single events.
+            if (qc + 1 < nsets && nev < 64) {  // (uniform)
+              int total = nev;
+              bool staged = false;
+              auto append = [&](int bq, uint32_t cq) {
+                const bool pq = bq >= 0 && cq == static_cast<uint32_t>(bv);
+                const unsigned long long mq = __ballot(pq);
+                if (mq) {
+                  if (!staged) {
+                    if (part) evb[__popcll(partmask & lt_mask)] = static_cast<uint16_t>(b);
+                    staged = true;
+                  }
+                  const int at = total + static_cast<int>(__popcll(mq & lt_mask));
+                  if (pq && at < 64) evb[at] = static_cast<uint16_t>(bq);
+                  total += static_cast<int>(__popcll(mq));
+                }
+              };
+  #pragma unroll
+              for (int q = 1; q < 4; ++q)
+                if (q > qc && q < nsets && total < 64) append(mybin[q], cntq[q]);  // (uniform)
+              for (int q = qc + 1 > 4 ? qc + 1 : 4; q < nsets && total < 64; ++q) {
+                const int t = lane + 64 * q;
+                const int bq = t < nnz ? static_cast<int>(nzlist[t]) : -1;
+                append(bq, bq >= 0 ? static_cast<uint32_t>(hist[bq]) : 0u);
+              }
+              if (staged) {
+                asm volatile("" ::: "memory");  // (LDS executes a wave's operations in order)
+                __builtin_amdgcn_wave_barrier();
+                nev = total < 64 ? total : 64;
+                part = lane < nev;
+                b = part ? static_cast<int>(evb[lane]) : -1;
+                partmask = nev == 64 ? ~0ull : ((1ull << nev) - 1ull);
+              }
+            }
             const int bs = b >= 0 ? b : 0;
             tb = DPX_STAMP();
-            const unsigned long long partmask = __ballot(part);
-            const int nev = static_cast<int>(__popcll(partmask));
             if (nev < kSweepMinEvents) {
               // A few events only (frames with a few large planes spend most rounds here: the fullest bins differ in count).
               // Too little to run in parallel for what a sweep round costs, so only the first event is taken, without
