@@ -50,6 +50,16 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
   return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(x), 63));
 }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) { return ~wave_max_u32(~x); }
+// inclusive prefix sum over the 64 lanes (DPP row shifts / broadcasts)
+__device__ __forceinline__ int wave_incl_scan_i32(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+  return x;
+}
 
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -107,7 +117,8 @@ __host__ __device__ constexpr int claim_bits(int) { return 12; }
 // the BFS reads its batch from (a batch is at most 128 entries behind the tail unless the frontier is wider than the ring).
 constexpr int kRingBits = 13;
 // the bins of a sweep round's events when they come from several 64-bin chunks (64 x uint16, behind the claim table)
-constexpr uint32_t kEvBytes = 128;
+// + the staging of a round's items: 64 x 16-byte records, 64 results, 64 source lanes
+constexpr uint32_t kEvBytes = 128 + 16 + 1024 + 256 + 64;
 // one-wave tier-0 grow launch (split form): small claim table and ring, so that several frames' grow waves share a CU
 #ifndef DPX_LEAN_CLAIM_BITS
 #define DPX_LEAN_CLAIM_BITS 10
@@ -495,7 +506,12 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
     uint32_t* bclaim = candc + nb;
     uint32_t* ctab = bclaim + nb;
     uint16_t* evb = reinterpret_cast<uint16_t*>(ctab + (1 << kClaimBits));
-    uint32_t* ring = ctab + (1 << kClaimBits) + (kEvBytes >> 2);  // tier 0 only
+    // round staging behind the event bins: a 16-byte record per lane (list, seed, first item), per-lane results, the
+    // source lane of every item
+    uint4* rrec = reinterpret_cast<uint4*>(smem + ((static_cast<uint32_t>(reinterpret_cast<unsigned char*>(evb + 64) - smem) + 15u) & ~15u));
+    uint32_t* rres = reinterpret_cast<uint32_t*>(rrec + 64);
+    uint8_t* rsrc = reinterpret_cast<uint8_t*>(rres + 64);
+    uint32_t* ring = ctab + (1 << kClaimBits) + (kEvBytes >> 2);  // tier 0 only (kEvBytes is a multiple of 4)
     constexpr uint32_t kRingMask = (1u << kRingBitsL) - 1u;
     auto claim_slot = [&](uint32_t k) { return (k * 2654435761u) >> (32 - kClaimBits); };
     if (TIER != 2 && wid == 0) {
@@ -885,7 +901,8 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
             // of its seed, and an empty byte (0) matches no code.  In-edge bits make the L / R steps across a row end and the
             // bounds test the U / D steps across the grid's first / last row fail, as in the wave-wide BFS.  A lone wave is
             // bound by its instruction count, so the accept tests come first and the list work runs only where a lane accepts.
-            uint32_t l0 = 0x88u, l1 = 0u;
+            static_assert(kSpecMax == 8, "the list of a speculative grow is the eight bytes of a 64-bit register pair");
+            unsigned long long ll = 0x88ull;
             int n = 1, hpop = 0;
             bool complete = !big;
             bool act = part && !big;
@@ -902,7 +919,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
             const unsigned long long t_sp0 = DPX_STAMP();
             while (__ballot(act)) {
               if (DBG) ++n_pops;
-              const uint32_t code = act ? ((hpop < 4 ? (l0 >> (8 * hpop)) : (l1 >> (8 * (hpop - 4)))) & 0xFFu) : 0x88u;
+              const uint32_t code = act ? (static_cast<uint32_t>(ll >> (8 * hpop)) & 0xFFu) : 0x88u;
               const int cr = static_cast<int>(code >> 4), cc = static_cast<int>(code & 15u);
               const int u = cs + (cr - 8) * nh + (cc - 8);
               // (unclamped reads: u is a grid cell, its neighbours' bytes lie inside the flag array or its nh guard bytes)
@@ -912,27 +929,28 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
               const bool okD = act && u + nh < C && ((fD & (fD >> 2)) & 1u) != 0u;
               const bool okL = act && u >= 1 && ((fL & (fL >> 5)) & 1u) != 0u;
               const bool okR = act && u + 1 < C && ((fR & (fR >> 4)) & 1u) != 0u;
-              auto visit = [&](bool ok, int vr, int vc) {
-                const bool far = vr == 0 || vr == 16 || vc == 0 || vc == 16;  // 8 rows / columns away: not in the list (only when n == 8)
-                const uint32_t vcode = (static_cast<uint32_t>(vr) << 4) | static_cast<uint32_t>(vc);
-                const uint32_t rep = (vcode & 0xFFu) * 0x01010101u;
-                const uint32_t x0 = l0 ^ rep, x1 = l1 ^ rep;
-                const bool dup = !far && ((((x0 - 0x01010101u) & ~x0) | ((x1 - 0x01010101u) & ~x1)) & 0x80808080u) != 0u;
+              // A neighbour's code is code -+ 16 (U / D) or -+ 1 (L / R).  A list entry has both nibbles in 1..15 (at most
+              // seven rows / columns from the seed); a neighbour eight away — possible only when the list is full — has a
+              // zero nibble in its low byte, matches no entry and no empty byte, and ends the speculation like any other
+              // ninth cell.
+              auto visit = [&](bool ok, uint32_t vcode) {
+                const uint32_t rep = __builtin_amdgcn_perm(0u, vcode, 0u);  // the low byte in all four bytes
+                const uint32_t x0 = static_cast<uint32_t>(ll) ^ rep, x1 = static_cast<uint32_t>(ll >> 32) ^ rep;
+                const bool dup = ((((x0 - 0x01010101u) & ~x0) | ((x1 - 0x01010101u) & ~x1)) & 0x80808080u) != 0u;
                 if (ok && act && !dup) {
                   if (n == kSpecMax) {
                     complete = false;
                     act = false;
                   } else {
-                    if (n < 4) l0 |= vcode << (8 * n);
-                    else l1 |= vcode << (8 * (n - 4));
+                    ll |= static_cast<unsigned long long>(vcode & 0xFFu) << (8 * n);
                     ++n;
                   }
                 }
               };
-              if (__ballot(okU)) visit(okU, cr - 1, cc);
-              if (__ballot(okD)) visit(okD, cr + 1, cc);
-              if (__ballot(okL)) visit(okL, cr, cc - 1);
-              if (__ballot(okR)) visit(okR, cr, cc + 1);
+              if (__ballot(okU)) visit(okU, code - 16u);
+              if (__ballot(okD)) visit(okD, code + 16u);
+              if (__ballot(okL)) visit(okL, code - 1u);
+              if (__ballot(okR)) visit(okR, code + 1u);
               ++hpop;
               if (hpop >= n) act = false;
               if (act && hpop >= maxpops) {  // (see maxpops)
@@ -946,65 +964,72 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
                 act = false;
               }
             }
+            const uint32_t l0 = static_cast<uint32_t>(ll), l1 = static_cast<uint32_t>(ll >> 32);
             if (DBG) a_spec += DPX_STAMP() - t_sp0;
             const unsigned long long t_cl0 = DPX_STAMP();
             // 5. which events fire.  Rounds in which every grow is a single cell need no claims: the seeds are distinct
             // cells of distinct bins.  Otherwise every complete lane claims its cells, and the bins of its non-seed cells,
             // with min(lane); every lane then reads the lowest claimant of its bin (lowb) and of its cells (lowc).
-            const bool spec = part && complete;
-            const unsigned long long multi = __ballot(spec && n > 1);
-            uint32_t lowb = 0xFFFFFFFFu, lowc = 0xFFFFFFFFu;
-            int cell[kSpecMax], cbin[kSpecMax];
-            cell[0] = cs;
-            cbin[0] = b;
-  #pragma unroll
-            for (int i = 1; i < kSpecMax; ++i) {
-              cell[i] = cs;
-              cbin[i] = -1;
+            // The non-seed cells of all lanes are handled as ITEMS, one wave lane each (a round has 15-20 of them on a noisy
+            // frame, while a loop over list positions runs seven times for every lane): item k = (source lane, list index)
+            // through an exclusive prefix sum of the list lengths, the source lane scattered into a byte array; a lane's
+            // list and seed travel through a 16-byte record.  Lists beyond the 64th item are given up (any give-up is exact).
+            bool spec = part && complete;
+            int cnt = spec ? n - 1 : 0;
+            int incl_items = wave_incl_scan_i32(cnt);
+            if (cnt > 0 && incl_items > 64) {
+              complete = false;
+              spec = false;
+              cnt = 0;
             }
-            // (longest complete grow of the round, wave-uniform: the unrolled loops below stop there with a scalar test)
-            const int nmax = multi ? static_cast<int>(wave_max_u32(spec ? static_cast<uint32_t>(n) : 0u)) : 1;
+            const unsigned long long multi = __ballot(cnt > 0);
+            uint32_t lowb = 0xFFFFFFFFu, lowc = 0xFFFFFFFFu;
+            bool it_ok = false;
+            int it_src = 0, it_cell = 0, it_bin = -1, it_i = 0;
             if (multi) {
-  #pragma unroll
-              for (int i = 1; i < kSpecMax; ++i) {
-                if (i < nmax) {
-                  const uint32_t code = (i < 4 ? (l0 >> (8 * i)) : (l1 >> (8 * (i - 4)))) & 0xFFu;
-                  const bool have = spec && i < n;
-                  cell[i] = have ? cs + (static_cast<int>(code >> 4) - 8) * nh + (static_cast<int>(code & 15u) - 8) : cs;
-                  int bn = 0;
-                  if (have) bn = HASBIN ? static_cast<int>(binof[cell[i]]) : static_cast<int>(meta[cell[i]] >> META_BIN_SHIFT);
-                  cbin[i] = (bn - 1 < nb) ? bn - 1 : -1;
-                }
-              }
-              if (spec) atomicMin(&ctab[claim_slot(static_cast<uint32_t>(cs))], static_cast<uint32_t>(lane));
+              const int off = incl_items - cnt;
+              const int nitems = static_cast<int>(wave_max_u32(cnt > 0 ? static_cast<uint32_t>(incl_items) : 0u));
+              rrec[lane] = make_uint4(l0, l1, static_cast<uint32_t>(cs), static_cast<uint32_t>(off));
+              rres[lane] = 0xFFFFFFFFu;
   #pragma unroll
               for (int i = 1; i < kSpecMax; ++i)
-                if (i < nmax && spec && i < n) {
-                  atomicMin(&ctab[claim_slot(static_cast<uint32_t>(cell[i]))], static_cast<uint32_t>(lane));
-                  if (cbin[i] >= 0) atomicMin(&bclaim[cbin[i]], static_cast<uint32_t>(lane));
-                }
+                if (i <= cnt) rsrc[off + i - 1] = static_cast<uint8_t>(lane);
               asm volatile("" ::: "memory");  // (LDS executes a wave's operations in order; only the compiler must keep it)
+              __builtin_amdgcn_wave_barrier();
+              it_ok = lane < nitems;
+              if (it_ok) {
+                it_src = static_cast<int>(rsrc[lane]);
+                const uint4 r = rrec[it_src];
+                it_i = lane - static_cast<int>(r.w) + 1;
+                const unsigned long long ll = (static_cast<unsigned long long>(r.y) << 32) | r.x;
+                const uint32_t code = static_cast<uint32_t>(ll >> (8 * it_i)) & 0xFFu;
+                it_cell = static_cast<int>(r.z) + (static_cast<int>(code >> 4) - 8) * nh + (static_cast<int>(code & 15u) - 8);
+                const int bn = HASBIN ? static_cast<int>(binof[it_cell]) : static_cast<int>(meta[it_cell] >> META_BIN_SHIFT);
+                it_bin = (bn - 1 < nb) ? bn - 1 : -1;
+              }
+              if (spec) atomicMin(&ctab[claim_slot(static_cast<uint32_t>(cs))], static_cast<uint32_t>(lane));
+              if (it_ok) {
+                atomicMin(&ctab[claim_slot(static_cast<uint32_t>(it_cell))], static_cast<uint32_t>(it_src));
+                if (it_bin >= 0) atomicMin(&bclaim[it_bin], static_cast<uint32_t>(it_src));
+              }
+              asm volatile("" ::: "memory");
               __builtin_amdgcn_wave_barrier();
               if (part) {  // (incomplete grows read too: whether their bin / seed is still theirs decides skip or wide BFS)
                 lowb = bclaim[b];
                 lowc = ctab[claim_slot(static_cast<uint32_t>(cs))];
-  #pragma unroll
-                for (int i = 1; i < kSpecMax; ++i)
-                  if (i < nmax && spec && i < n) {
-                    const uint32_t m = ctab[claim_slot(static_cast<uint32_t>(cell[i]))];
-                    lowc = m < lowc ? m : lowc;
-                  }
               }
+              if (it_ok) atomicMin(&rres[it_src], ctab[claim_slot(static_cast<uint32_t>(it_cell))]);
               asm volatile("" ::: "memory");
               __builtin_amdgcn_wave_barrier();
-              if (spec) {  // leave the table clean for the next round
-                ctab[claim_slot(static_cast<uint32_t>(cs))] = 0xFFFFFFFFu;
-  #pragma unroll
-                for (int i = 1; i < kSpecMax; ++i)
-                  if (i < nmax && i < n) {
-                    ctab[claim_slot(static_cast<uint32_t>(cell[i]))] = 0xFFFFFFFFu;
-                    if (cbin[i] >= 0) bclaim[cbin[i]] = 0xFFFFFFFFu;
-                  }
+              if (cnt > 0) {
+                const uint32_t m = rres[lane];
+                lowc = m < lowc ? m : lowc;
+              }
+              // leave the tables clean for the next round
+              if (spec) ctab[claim_slot(static_cast<uint32_t>(cs))] = 0xFFFFFFFFu;
+              if (it_ok) {
+                ctab[claim_slot(static_cast<uint32_t>(it_cell))] = 0xFFFFFFFFu;
+                if (it_bin >= 0) bclaim[it_bin] = 0xFFFFFFFFu;
               }
             }
             // Lanes in order; only the flagged ones need a look.  A lane whose bin lost a cell to a lower lane THAT FIRES is no
@@ -1074,15 +1099,16 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
                 atomicSub(&hist[b], 1);  // hist.removePoint
                 grow_start[ngrow + grank] = static_cast<uint32_t>(base);
               }
-              if (multi & cm) {
-  #pragma unroll
-                for (int i = 1; i < kSpecMax; ++i)
-                  if (i < nmax && cmt && i < n) {
-                    const int v = cell[i];
-                    queue[base + i] = static_cast<idx_t>(v);
-                    atomicAnd(reinterpret_cast<uint32_t*>(flags + (v & ~3)), ~(F_UNASSIGNED << ((v & 3) * 8)));
-                    if (cbin[i] >= 0) atomicSub(&hist[cbin[i]], 1);
-                  }
+              if (multi & cm) {  // the non-seed cells, item by item: queue slot, flag bit, histogram
+                rres[lane] = static_cast<uint32_t>(base);
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                if (it_ok && ((cm >> it_src) & 1ull) != 0ull) {
+                  const int v = it_cell;
+                  queue[static_cast<int>(rres[it_src]) + it_i] = static_cast<idx_t>(v);
+                  atomicAnd(reinterpret_cast<uint32_t*>(flags + (v & ~3)), ~(F_UNASSIGNED << ((v & 3) * 8)));
+                  if (it_bin >= 0) atomicSub(&hist[it_bin], 1);
+                }
               }
               if (wantmask) {
                 const int crank = static_cast<int>(__popcll(wantmask & lt_mask));
