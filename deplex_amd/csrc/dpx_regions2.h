@@ -235,7 +235,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
   unsigned long long t_start = DPX_STAMP(), t_p0 = 0, t_p1 = 0, t_p2 = 0, t_p3 = 0, t_p4 = 0, t_p5 = 0;
   const unsigned long long t_res = (PHASE > 0 && rx.res) ? static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) : 0ull;
   const unsigned long long t_real = ((PHASE == 2 || PHASE == 4) && rx.res) ? static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()) : 0ull;
-  unsigned long long a_argmax = 0, a_seed = 0, a_bfs = 0, n_steps = 0, n_spec = 0, n_rounds = 0, n_scan1 = 0, n_scan64 = 0, a_scan = 0, a_spec = 0, n_pops = 0, n_stop_inc = 0, n_stop_bin = 0, n_stop_cell = 0, a_claims = 0, a_commit = 0, n_fast = 0, a_fast = 0;
+  unsigned long long a_argmax = 0, a_seed = 0, a_bfs = 0, n_steps = 0, n_spec = 0, n_rounds = 0, n_scan1 = 0, n_scan64 = 0, a_scan = 0, a_spec = 0, n_pops = 0, n_stop_inc = 0, n_stop_bin = 0, n_stop_cell = 0, a_claims = 0, a_commit = 0, n_fast = 0, a_fast = 0, n_gather = 0, n_itemover = 0;
   const int frame = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int C = prm.C, nh = prm.nh, nv = prm.nv;
@@ -750,6 +750,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
                 append(bq, bq >= 0 ? static_cast<uint32_t>(hist[bq]) : 0u);
               }
               if (staged) {
+                if (DBG) ++n_gather;
                 asm volatile("" ::: "memory");  // (LDS executes a wave's operations in order)
                 __builtin_amdgcn_wave_barrier();
                 nev = total < 64 ? total : 64;
@@ -977,6 +978,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
             bool spec = part && complete;
             int cnt = spec ? n - 1 : 0;
             int incl_items = wave_incl_scan_i32(cnt);
+            if (DBG) n_itemover += __popcll(__ballot(cnt > 0 && incl_items > 64));
             if (cnt > 0 && incl_items > 64) {
               complete = false;
               spec = false;
@@ -1811,7 +1813,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
       d[0] = t_p0 - t_start; d[1] = t_p1 - t_p0; d[2] = t_p2 - t_p1; d[3] = t_p3 - t_p2; d[4] = t_p4 - t_p3;
       d[5] = t_p5 - t_p4; d[6] = t_end - t_p5; d[7] = t_end - t_start;
       d[8] = a_argmax; d[9] = a_seed; d[10] = a_bfs; d[11] = n_rounds | (n_spec << 32); d[12] = n_steps; d[13] = ngrow; d[14] = ncand; d[15] = activations;
-      d[16] = a_scan; d[17] = a_spec; d[18] = n_scan1; d[19] = n_scan64; d[20] = n_pops; d[21] = n_stop_inc; d[22] = n_stop_bin; d[23] = n_stop_cell; d[24] = a_claims; d[25] = a_commit; d[26] = n_fast; d[27] = a_fast;
+      d[16] = a_scan; d[17] = a_spec; d[18] = n_scan1; d[19] = n_scan64; d[20] = n_pops; d[21] = n_stop_inc; d[22] = n_stop_bin; d[23] = n_stop_cell; d[24] = a_claims; d[25] = a_commit; d[26] = n_fast; d[27] = a_fast; d[28] = n_gather; d[29] = n_itemover;
     }
   }
 }

@@ -397,6 +397,35 @@ def test_sweep_rounds_quilt_scenes(D, oracle, env):
             del os.environ[env]
 
 
+def test_sweep_round_paths_are_exercised(D, oracle):
+    """The two bounded structures of a sweep round — the 64-entry staging of events gathered from several chunks of the
+    bin list, and the 64 items (non-seed cells) a round can claim — are hit by a quilt of many tilt directions: the
+    diagnostic instantiation counts rounds that gathered and grows given up beyond the 64th item, and the results equal
+    the oracle's all the same (tier 1 and tier 0)."""
+    from deplex_amd import _capi
+    depth = np.stack([synth.quilt_depth(960, 1280, seed=11, kmax=3, ntilt=90), synth.quilt_depth(960, 1280, seed=12, kmax=2, ntilt=150, jitter=0.2)])
+    intr = synth.intrinsics_for(960, 1280)
+    for env in (None, "DPX_REGIONS_GSTATE"):
+        if env:
+            os.environ[env] = "1"
+        try:
+            full_compare(D, oracle, depth, intr, oracle.default_config())
+            ex = D.PlaneExtractor(960, 1280, max_batch=2)
+            _capi.check(_capi.lib().dpx_debug_region_phases(ex._h, 1, 0, None))
+            ex.process_depth_batch(depth, *intr)
+            gathered = over = 0
+            for f in range(2):
+                out = np.zeros(32, dtype=np.uint64)
+                _capi.check(_capi.lib().dpx_debug_region_phases(ex._h, 1, f, out.ctypes.data))
+                gathered += int(out[28])
+                over += int(out[29])
+            assert gathered > 0, "no round took events from several chunks"
+            assert over > 0, "no round ran into the item limit"
+        finally:
+            if env:
+                del os.environ[env]
+
+
 def test_fast_division_is_verified(D):
     """The reciprocal division of the fast plane-fit kernel is accepted only after an exhaustive device-side check
     against IEEE division for the frame geometry; the fixtures' intrinsics (including ICL's negative fy) pass it."""

@@ -26,7 +26,8 @@ names = ["P0 load", "P1 seeds+bfs", "P2 accum", "P3 fits", "P4 labels", "P5 merg
          "sum argmax", "sum seeds+spec", "sum bfs", "rounds|spec_grows<<32", "bfs steps", "grows", "cands", "activations",
          "cyc scans", "cyc spec", "lane scan steps", "wave scan steps", "spec pops",
          "stops: large grow", "stops: bin touched", "stops: cell taken",
-         "cyc claims", "cyc resolve+commit", "single-event rounds", "cyc single-event rounds"]
+         "cyc claims", "cyc resolve+commit", "single-event rounds", "cyc single-event rounds", "rounds with events from several chunks",
+         "grows given up beyond the 64th item"]
 for f in (range(B) if B <= 8 else sorted(set((0, 1, B - 1)))):
     out = np.zeros(32, dtype=np.uint64)
     _capi.check(_capi.lib().dpx_debug_region_phases(ex._h, 1, f, out.ctypes.data))
