@@ -885,7 +885,7 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
       const bool fits1 = C < 65000 && std::max<size_t>(l1.tail_end, l1.grow_end) <= kLdsLimit;
       const bool fits0 = C < (size_t(1) << dpx::kKeyCellBits) && std::max<size_t>(l0.tail_end, l0.grow_end) <= kLdsLimit;
       // Mid-size frames in stream mode (slots of a dpx_pipeline; DPX_REGIONS_GSPLIT=1 forces it for any handle): tier 0 in
-      // split form.  Its one-wave grow launch holds the flag bytes and a small scratch (28 KB for 1280x960) instead of
+      // split form.  Its one-wave grow launch holds the flag bytes and a small scratch (29.5 KB for 1280x960) instead of
       // tier 1's 9 B per cell (135 KB): five frames' grow waves per CU instead of one.  A frame's own latency is ~10 %
       // longer (queues and seed lists in global memory), a stream of batches faster by a third and more (DESIGN.md
       // section 5).  Taken for frames beyond tier 2 when at least two such launches fit a CU.

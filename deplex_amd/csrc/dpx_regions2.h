@@ -17,8 +17,10 @@
 //   * large frames (tiers 1 and 0) do not take one grow after the other: the bins that stand at the histogram's maximum
 //     fire in ascending order and do not influence each other unless their grows touch, so up to 64 of them are grown
 //     speculatively at once, one lane each, checked against each other with claim tables and committed together
-//     ("sweep rounds", see the comment in the grow phase: 18 776 grows of a noisy 3840x2160 frame in ~4 100 rounds);
-//   * tier 0 also exists as three launches with a ONE-wave grow launch that keeps 28 KB of LDS for a 1280x960 frame:
+//     ("sweep rounds", see the comment in the grow phase: 18 776 grows of a noisy 3840x2160 frame in ~2 500 rounds; a
+//     round gathers the bins at the level from all 64-bin chunks of the bin list, and the non-seed cells of its grows
+//     are claimed and committed as flattened items, one lane each);
+//   * tier 0 also exists as three launches with a ONE-wave grow launch that keeps 29.5 KB of LDS for a 1280x960 frame:
 //     what the slots of a pipeline take, because then five frames' grow waves share a CU;
 //   * wave reductions use DPP row shifts / broadcasts (gfx9) instead of ds_bpermute butterflies;
 //   * the parallel phases (state load, sort, float accumulation of the grown segments, f64 segment fits, label
