@@ -79,6 +79,8 @@ SYMBOLS = {
     "dpx_pipeline_destroy": (None, [C.c_void_p]),
     "dpx_pipeline_submit_depth": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "dpx_pipeline_submit_depth_cells": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "dpx_pipeline_submit_depth_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "dpx_pipeline_submit_depth_cells_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "dpx_pipeline_submit_depth_many": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_void_p)]),
     "dpx_pipeline_submit_pcd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "dpx_pipeline_sync": (C.c_int, [C.c_void_p]),

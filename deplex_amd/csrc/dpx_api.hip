@@ -1368,6 +1368,11 @@ struct dpx_pipeline_s {
   std::vector<std::vector<SubBatch>> pending;  // per slot: submissions recorded, not launched yet
   std::vector<char> pending_depth;             // per slot: input form of the pending submissions (1 depth, 0 cloud)
   std::vector<char> pending_cells;             // per slot: output form (1 = cell labels into the submissions' buffers, 0 = pixel label maps)
+  // host-buffer submissions (dpx_pipeline_submit_depth*_host): per slot a device staging buffer for the group's depth
+  // frames and one for its pixel label maps (allocated at the first such submission), and per pending submission the host
+  // address its result goes to (nullptr: a device-buffer submission)
+  std::vector<void*> stage_in, stage_out;
+  std::vector<std::vector<void*>> pending_host;
   int group = 1, batch = 0;
   long long submitted = 0;
   int device = 0;
@@ -1383,14 +1388,21 @@ int pipeline_flush(dpx_pipeline p, size_t k) {
   if (cells) h->no_pixel_labels = true;  // cell-level submissions: no label expansion launch, the merged cell labels are copied out
   if (rc == DPX_OK) rc = stage_rest(h, p->pending[k].data(), nsub, p->batch, p->pending_depth[k] != 0, h->stream);
   h->no_pixel_labels = false;
-  if (rc == DPX_OK && cells) {
-    const size_t per = static_cast<size_t>(p->batch) * h->prm.C;
-    for (int j = 0; j < nsub && rc == DPX_OK; ++j)
-      if (hipMemcpyAsync(p->pending[k][j].d_labels, h->d_cell_labels + static_cast<size_t>(j) * per, per * sizeof(int32_t), hipMemcpyDeviceToDevice,
-                         h->stream) != hipSuccess)
-        rc = fail(DPX_ERR_HIP, "hipMemcpyAsync (cell labels) failed");
+  // results that do not stay where the kernels wrote them: cell labels leave the slot's buffer (device to device, or
+  // straight to the host for a host-buffer submission), pixel maps of host-buffer submissions leave the staging buffer
+  const size_t per = static_cast<size_t>(p->batch) * h->prm.C, per_px = static_cast<size_t>(p->batch) * h->prm.N;
+  for (int j = 0; j < nsub && rc == DPX_OK; ++j) {
+    void* hdst = p->pending_host[k][j];
+    hipError_t e = hipSuccess;
+    if (cells)
+      e = hipMemcpyAsync(hdst ? hdst : static_cast<void*>(p->pending[k][j].d_labels), h->d_cell_labels + static_cast<size_t>(j) * per,
+                         per * sizeof(int32_t), hdst ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, h->stream);
+    else if (hdst)
+      e = hipMemcpyAsync(hdst, p->pending[k][j].d_labels, per_px * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
+    if (e != hipSuccess) rc = fail(DPX_ERR_HIP, "hipMemcpyAsync (results) failed");
   }
   p->pending[k].clear();
+  p->pending_host[k].clear();
   return rc;
 }
 }  // namespace
@@ -1419,6 +1431,9 @@ int dpx_pipeline_create(const dpx_config* cfg, int32_t image_height, int32_t ima
   p->pending.resize(p->slots.size());
   p->pending_depth.assign(p->slots.size(), 1);
   p->pending_cells.assign(p->slots.size(), 0);
+  p->stage_in.assign(p->slots.size(), nullptr);
+  p->stage_out.assign(p->slots.size(), nullptr);
+  p->pending_host.resize(p->slots.size());
   // HIP binds a stream to a hardware queue at its first use: do that here, once, for every slot, instead of inside the
   // first groups a caller submits
   for (auto h : p->slots) (void)hipMemsetAsync(h->d_stats, 0, sizeof(dpx_frame_stats), h->stream);
@@ -1432,12 +1447,16 @@ void dpx_pipeline_destroy(dpx_pipeline p) {
   (void)hipSetDevice(p->device);
   (void)hipDeviceSynchronize();
   for (auto h : p->slots) dpx_destroy(h);
+  for (void* b : p->stage_in) (void)hipFree(b);
+  for (void* b : p->stage_out) (void)hipFree(b);
   delete p;
 }
 
 namespace {
+// host = true: d_in / d_labels are HOST addresses (page-locked for the copies to be asynchronous); the frames are copied
+// into the slot's staging buffer on the slot's stream right here, the results back after the group's kernels
 int pipeline_submit(dpx_pipeline p, const void* d_in, bool depth, int32_t batch, float fx, float fy, float cx, float cy, void* d_labels,
-                    bool cells = false) {
+                    bool cells = false, bool host = false) {
   if (!p || !d_in || !d_labels) return fail(DPX_ERR_ARG, "bad argument");
   if (cells && !p->slots.empty() && p->slots[0]->cfg.ransac_refinement)
     return fail(DPX_ERR_ARG, "cell-level output is not defined with ransac_refinement (it edits single pixels)");
@@ -1457,6 +1476,19 @@ int pipeline_submit(dpx_pipeline p, const void* d_in, bool depth, int32_t batch,
   dpx_handle h = p->slots[k];
   // the submission is only recorded here: the plane fit of the whole group is ONE launch, issued with the region
   // stage when the group is full (or at dpx_pipeline_sync)
+  void* hdst = nullptr;
+  if (host) {
+    DPX_HIP(hipSetDevice(p->device));
+    const size_t in_bytes = static_cast<size_t>(p->batch) * h->prm.N * sizeof(uint16_t), out_bytes = static_cast<size_t>(p->batch) * h->prm.N * sizeof(int32_t);
+    if (!p->stage_in[k]) DPX_HIP(hipMalloc(&p->stage_in[k], in_bytes * static_cast<size_t>(p->group)));
+    if (!cells && !p->stage_out[k]) DPX_HIP(hipMalloc(&p->stage_out[k], out_bytes * static_cast<size_t>(p->group)));
+    void* din = static_cast<char*>(p->stage_in[k]) + in_bytes * static_cast<size_t>(j);
+    DPX_HIP(hipMemcpyAsync(din, d_in, in_bytes, hipMemcpyHostToDevice, h->stream));
+    hdst = d_labels;
+    d_in = din;
+    // (cell-level: the result is copied from the slot's cell labels; the SubBatch's own address is not written)
+    d_labels = cells ? static_cast<void*>(h->d_cell_labels) : static_cast<void*>(static_cast<char*>(p->stage_out[k]) + out_bytes * static_cast<size_t>(j));
+  }
   SubBatch sb;
   int rc = fill_sub(h, sb, d_in, static_cast<int32_t*>(d_labels), depth, fx, fy, cx, cy);
   if (rc) return rc;
@@ -1464,6 +1496,7 @@ int pipeline_submit(dpx_pipeline p, const void* d_in, bool depth, int32_t batch,
   p->pending_depth[k] = depth ? 1 : 0;
   p->pending_cells[k] = cells ? 1 : 0;
   p->pending[k].push_back(sb);
+  p->pending_host[k].push_back(hdst);
   if (j == p->group - 1) rc = pipeline_flush(p, k);
   return rc;
 }
@@ -1477,6 +1510,16 @@ int dpx_pipeline_submit_depth(dpx_pipeline p, const void* d_depth, int32_t batch
 int dpx_pipeline_submit_depth_cells(dpx_pipeline p, const void* d_depth, int32_t batch, float fx, float fy, float cx, float cy,
                                     void* d_cell_labels) {
   return pipeline_submit(p, d_depth, true, batch, fx, fy, cx, cy, d_cell_labels, /*cells=*/true);
+}
+
+int dpx_pipeline_submit_depth_host(dpx_pipeline p, const uint16_t* h_depth, int32_t batch, float fx, float fy, float cx, float cy,
+                                   int32_t* h_labels) {
+  return pipeline_submit(p, h_depth, true, batch, fx, fy, cx, cy, h_labels, /*cells=*/false, /*host=*/true);
+}
+
+int dpx_pipeline_submit_depth_cells_host(dpx_pipeline p, const uint16_t* h_depth, int32_t batch, float fx, float fy, float cx, float cy,
+                                         int32_t* h_cell_labels) {
+  return pipeline_submit(p, h_depth, true, batch, fx, fy, cx, cy, h_cell_labels, /*cells=*/true, /*host=*/true);
 }
 
 int dpx_pipeline_submit_depth_many(dpx_pipeline p, int32_t n, const void* const* d_depth, int32_t batch, float fx, float fy, float cx,

@@ -276,6 +276,7 @@ class Pipeline:
     def __init__(self, image_height: int, image_width: int, config: Optional[Config] = None, *, batch: int = 64,
                  slots: int = 16, group: int = 1, device: int = 0):
         self._p = C.c_void_p()
+        self._keep = []  # host arrays of submissions in flight (submit_depth_host)
         cfg = config if config is not None else Config()
         self.config, self.device = cfg, int(device)
         self.image_height, self.image_width, self.batch, self.slots = int(image_height), int(image_width), int(batch), int(slots)
@@ -290,6 +291,18 @@ class Pipeline:
         """Cell-level output: int32 [batch][nv][nh] merged cell labels into device memory, no pixel label map (no label
         expansion launch for the group)."""
         _capi.check(_capi.lib().dpx_pipeline_submit_depth_cells(self._p, d_depth_ptr, batch, fx, fy, cx, cy, d_cell_labels_ptr))
+
+    def submit_depth_host(self, depth: np.ndarray, fx, fy, cx, cy, out: np.ndarray, cells: bool = False) -> None:
+        """Host-buffer submission (dpx_pipeline_submit_depth_host / _cells_host): `depth` (batch, H, W) uint16 and `out`
+        (batch, H*W) int32 — or (batch, nv, nh) with cells=True — are HOST arrays, ideally page-locked (pinned_empty);
+        the slot's stream carries the copy in, the kernels and the copy out.  Both arrays are kept alive by the pipeline
+        and must not be touched until sync()."""
+        if depth.dtype != np.uint16 or not depth.flags.c_contiguous or out.dtype != np.int32 or not out.flags.c_contiguous:
+            raise TypeError("depth must be C-contiguous uint16, out C-contiguous int32")
+        batch = int(depth.shape[0])
+        fn = _capi.lib().dpx_pipeline_submit_depth_cells_host if cells else _capi.lib().dpx_pipeline_submit_depth_host
+        self._keep.append((depth, out))
+        _capi.check(fn(self._p, depth.ctypes.data, batch, fx, fy, cx, cy, out.ctypes.data))
 
     def submit_depth_many(self, d_depth_ptrs, batch: int, fx, fy, cx, cy, d_labels_ptrs) -> None:
         """len(d_depth_ptrs) submissions in one call (dpx_pipeline_submit_depth_many): same order and grouping as single calls."""
@@ -306,6 +319,7 @@ class Pipeline:
 
     def sync(self) -> None:
         _capi.check(_capi.lib().dpx_pipeline_sync(self._p))
+        self._keep.clear()
 
     def flush(self) -> None:
         """Launch what has been submitted so far without waiting (a partially filled group goes as it is)."""

@@ -186,6 +186,17 @@ int dpx_pipeline_submit_depth(dpx_pipeline p, const void* d_depth, int32_t batch
  * dpx_pipeline_slot() after dpx_pipeline_sync().  DPX_ERR_ARG with ransac_refinement. */
 int dpx_pipeline_submit_depth_cells(dpx_pipeline p, const void* d_depth, int32_t batch, float fx, float fy, float cx, float cy,
                                     void* d_cell_labels);
+/* HOST-buffer submissions: depth frames in host memory in, pixel label maps (batch x H x W int32) or cell labels
+ * (batch x nv x nh int32) in host memory out.  The frames are copied to a staging buffer of the slot on the slot's
+ * stream at submission, the results back after the group's kernels, so the copies of one slot overlap the kernels of
+ * the others (three slots keep the PCIe link busy: 90 k frames/s at 640x480 with cell labels, 38 k with pixel maps,
+ * DESIGN.md section 5).  Both buffers must stay valid and untouched until dpx_pipeline_sync(); page-locked memory
+ * (dpx_host_alloc) makes the copies asynchronous, pageable memory works but blocks in the call.  May be mixed with
+ * device-buffer submissions. */
+int dpx_pipeline_submit_depth_host(dpx_pipeline p, const uint16_t* h_depth, int32_t batch, float fx, float fy, float cx, float cy,
+                                   int32_t* h_labels);
+int dpx_pipeline_submit_depth_cells_host(dpx_pipeline p, const uint16_t* h_depth, int32_t batch, float fx, float fy, float cx,
+                                         float cy, int32_t* h_cell_labels);
 /* n submissions in one call (same batch size and intrinsics, one input and one output buffer each): what a caller that
  * already holds several batches does instead of n calls — the order and the grouping are those of n single calls. */
 int dpx_pipeline_submit_depth_many(dpx_pipeline p, int32_t n, const void* const* d_depth, int32_t batch, float fx, float fy,

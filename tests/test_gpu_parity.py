@@ -714,6 +714,45 @@ def test_pipeline_cell_level_submissions(D, oracle):
         D.Pipeline(240, 320, cfg, batch=3, slots=1, group=1).submit_depth_cells(d_in.data_ptr(), 3, *intr, outs[0].data_ptr())
 
 
+def test_pipeline_host_buffer_submissions(D, oracle):
+    """dpx_pipeline_submit_depth_host / _cells_host: frames from host memory (page-locked and pageable), pixel maps and cell
+    labels back in host memory, mixed with device-buffer submissions in one pipeline; all equal the oracle's label maps."""
+    import torch
+    depth = synth.synth_batch(3, 240, 320, seed0=140)
+    intr = synth.intrinsics_for(240, 320)
+    oracle.set_math("devmath")
+    ref = oracle.process_depth_batch(oracle.default_config(), depth, *intr)
+    ex = D.PlaneExtractor(240, 320, max_batch=3)
+    cl_ref, _ = ex.process_depth_batch_cells(depth, *intr, planes=False)
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(depth.view(np.int16)).to(dev)
+    for slots, group in ((3, 1), (2, 3)):
+        pipe = D.Pipeline(240, 320, D.Config(), batch=3, slots=slots, group=group)
+        pin_in = D.pinned_empty(depth.shape, np.uint16)
+        pin_in[:] = depth
+        outs = []
+        for i in range(11):
+            kind = i % 4
+            if kind == 0:    # page-locked in, page-locked pixel map out
+                o = D.pinned_empty((3, 240 * 320), np.int32); o[:] = -1
+                pipe.submit_depth_host(pin_in, *intr, o)
+            elif kind == 1:  # pageable in, pageable pixel map out
+                o = np.full((3, 240 * 320), -1, np.int32)
+                pipe.submit_depth_host(depth, *intr, o)
+            elif kind == 2:  # cell labels to the host
+                o = D.pinned_empty((3, 24, 32), np.int32); o[:] = -1
+                pipe.submit_depth_host(pin_in, *intr, o, cells=True)
+            else:            # a device-buffer submission in between
+                o = torch.full((3, 240 * 320), -1, dtype=torch.int32, device=dev)
+                pipe.submit_depth(d_in.data_ptr(), 3, *intr, o.data_ptr())
+            outs.append((kind, o))
+        pipe.sync()
+        for kind, o in outs:
+            got = o.cpu().numpy() if kind == 3 else np.asarray(o)
+            assert np.array_equal(got, cl_ref if kind == 2 else ref), (slots, group, kind)
+        del pipe
+
+
 def test_pipeline_group_of_many_submissions(D, oracle):
     """A group holds up to 32 submissions (the per-submission tables of the group launches are kernel arguments): 11
     single-frame submissions with alternating intrinsics in groups of 11 and of 32 (flushed partly filled by sync),

@@ -43,3 +43,28 @@ dt = rate(lambda: sh.process_depth_batch(pin_in, *intr, out=pin_out))
 print(f"{'sharded [0, 0], pixel labels, pinned':40s}: {dt * 1e3:6.2f} ms = {B / dt:8.0f} frames/s", flush=True)
 dt = rate(lambda: sh.process_depth_batch_cells(pin_in, *intr))
 print(f"{'sharded [0, 0], cell labels + planes':40s}: {dt * 1e3:6.2f} ms = {B / dt:8.0f} frames/s", flush=True)
+
+# streamed: host-buffer submissions of a pipeline (the slot's stream carries copy in, kernels, copy out; the copies of one
+# slot overlap the kernels of the others)
+R = 4
+pins = [D.pinned_empty(depth.shape, np.uint16) for _ in range(R)]
+for r in range(R):
+    pins[r][:] = synth.tum_stream(B, seed0=B * r)
+for slots in (2, 3, 4, 6):
+    pipe = D.Pipeline(480, 640, D.Config(), batch=B, slots=slots, group=1)
+    for k in range(slots):
+        pipe.slot(k).prepare_intrinsics(*intr)
+    for cells, shape in ((False, (B, N)), (True, (B, ex.nv, ex.nh))):
+        outs = [D.pinned_empty(shape, np.int32) for _ in range(slots + 1)]
+        n = 48
+
+        def run():
+            for i in range(n):
+                pipe.submit_depth_host(pins[i % R], *intr, outs[i % len(outs)], cells=cells)
+            pipe.sync()
+
+        run()
+        t0 = time.perf_counter(); run(); dt = (time.perf_counter() - t0) / n
+        print(f"{'pipeline host submissions, ' + ('cell labels' if cells else 'pixel labels') + f', {slots} slots':48s}: {dt * 1e3:6.2f} ms per {B} frames = "
+              f"{B / dt:8.0f} frames/s; H2D {B * 2 * N / dt / 1e9:5.1f} GB/s, D2H {outs[0].nbytes / dt / 1e9:5.2f} GB/s", flush=True)
+    del pipe
