@@ -48,9 +48,21 @@ int main(int argc, char** argv) {
       if (!pinned) throw std::runtime_error(dpx_last_error());
       deplex::ShardedExtractor sharded(h, w, {0, 0}, config, 2);
       sharded.processDepthBatch(frames.data(), B, K[0], K[4], K[2], K[5], pinned);
-      const bool same = std::equal(pix.begin(), pix.end(), pinned) && expanded == pix && std::equal(labels.begin(), labels.end(), pix.begin());
+      bool same = std::equal(pix.begin(), pix.end(), pinned) && expanded == pix && std::equal(labels.begin(), labels.end(), pix.begin());
+      // a stream of host batches: three in flight, pixel maps and cell labels
+      {
+        deplex::StreamExtractor stream(h, w, B, config);
+        std::vector<int32_t> out_a(pix.size(), -1), out_b(pix.size(), -1), out_c(cells.cell_labels.size(), -1);
+        std::fill(pinned, pinned + pix.size(), -1);
+        stream.submit(frames.data(), K[0], K[4], K[2], K[5], pinned);
+        stream.submit(frames.data(), K[0], K[4], K[2], K[5], out_a.data());
+        stream.submitCells(frames.data(), K[0], K[4], K[2], K[5], out_c.data());
+        stream.submit(frames.data(), K[0], K[4], K[2], K[5], out_b.data());
+        stream.sync();
+        same = same && std::equal(pix.begin(), pix.end(), pinned) && out_a == pix && out_b == pix && out_c == cells.cell_labels;
+      }
       dpx_host_free(pinned);
-      std::cout << "batch " << B << " cells_equal_pixels_equal_sharded " << (same ? 1 : 0) << " planes_frame0 " << cells.n_planes[0] << " total "
+      std::cout << "batch " << B << " cells_equal_pixels_equal_sharded_equal_streamed " << (same ? 1 : 0) << " planes_frame0 " << cells.n_planes[0] << " total "
                 << cells.planes.size() << "\n";
       if (!same) return 1;
     }

@@ -156,4 +156,36 @@ class ShardedExtractor {
   int32_t height_, width_, max_batch_;
   std::vector<PlaneExtractor> shards_;
 };
+
+/** A stream of HOST batches through one GPU (not in the reference): `slots` batches are in flight, each on its own
+ *  stream carrying copy in, kernels, copy out (dpx_pipeline_submit_depth_host / _cells_host), so the copies of one batch
+ *  overlap the kernels of the others.  Buffers handed to submit() must stay valid and untouched until sync(); page-locked
+ *  memory (dpx_host_alloc) makes the copies asynchronous.  Every submission has `batch` frames. */
+class StreamExtractor {
+ public:
+  StreamExtractor(int32_t image_height, int32_t image_width, int32_t batch, config::Config config = config::Config(), int32_t slots = 3,
+                  int32_t device = 0) {
+    const dpx_config c = config.to_c();
+    if (dpx_pipeline_create(&c, image_height, image_width, batch, device, slots, 1, &p_) != DPX_OK) throw std::runtime_error(dpx_last_error());
+    batch_ = batch;
+  }
+  ~StreamExtractor() { dpx_pipeline_destroy(p_); }
+  StreamExtractor(StreamExtractor const&) = delete;
+  StreamExtractor& operator=(StreamExtractor const&) = delete;
+  /** labels: batch x H x W int32 (the reference's label maps) */
+  void submit(uint16_t const* depth, float fx, float fy, float cx, float cy, int32_t* labels) {
+    if (dpx_pipeline_submit_depth_host(p_, depth, batch_, fx, fy, cx, cy, labels) != DPX_OK) throw std::runtime_error(dpx_last_error());
+  }
+  /** cell_labels: batch x nv x nh int32 (dpx_expand_cell_labels turns them into label maps on the host) */
+  void submitCells(uint16_t const* depth, float fx, float fy, float cx, float cy, int32_t* cell_labels) {
+    if (dpx_pipeline_submit_depth_cells_host(p_, depth, batch_, fx, fy, cx, cy, cell_labels) != DPX_OK) throw std::runtime_error(dpx_last_error());
+  }
+  void sync() {
+    if (dpx_pipeline_sync(p_) != DPX_OK) throw std::runtime_error(dpx_last_error());
+  }
+
+ private:
+  dpx_pipeline p_ = nullptr;
+  int32_t batch_ = 0;
+};
 }  // namespace deplex

@@ -1014,7 +1014,7 @@ def test_cpp_mirror_known_answer(tmp_path, tum_depth):
     assert r.returncode == 0, r.stderr + r.stdout
     assert "planes 34 labels 307200" in r.stdout
     # processDepthBatch == processDepthBatchCells expanded on the host == ShardedExtractor({0, 0}) == process()
-    assert "batch 5 cells_equal_pixels_equal_sharded 1 planes_frame0 34 total 170" in r.stdout
+    assert "batch 5 cells_equal_pixels_equal_sharded_equal_streamed 1 planes_frame0 34 total 170" in r.stdout
     assert "throws: Error! Invalid config parameter: patchSize(0). patchSize has to be positive." in r.stdout
     assert "throws: Error! Number of points doesn't match image shape: 307200 != 240 x 320" in r.stdout
     r = subprocess.run([str(exe), str(raw), "480", "640", str(synth.TUM_K), "/nonexistent.ini"], capture_output=True, text=True, timeout=300)

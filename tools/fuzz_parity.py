@@ -31,16 +31,40 @@ def fuzz_pipeline(rng, depth, intr, ocfg, xyz):
     else:
         d_in = torch.from_numpy(depth.view(np.int16)).to(dev)
     outs = [torch.full((B, H * W), -1, dtype=torch.int32, device=dev) for _ in range(nsub)]
+    # depth input: some submissions hand over HOST buffers (page-locked or pageable; pixel maps or, without the
+    # refinement, cell labels) between the device-buffer ones
+    ex0 = pipe.slot(0)
+    nvh = (ex0.nv, ex0.nh)
+    host_ok = not xyz
+    cells_ok = host_ok and not bool(ocfg.ransac_refinement)
+    pin_in = None
+    kinds = []
     for i in range(nsub):
+        kind = "dev"
+        if host_ok and rng.random() < 0.4:
+            kind = "cells" if (cells_ok and rng.random() < 0.4) else ("pin" if rng.random() < 0.6 else "page")
+        kinds.append(kind)
         if xyz:
             pipe.submit_pcd(d_in.data_ptr(), B, outs[i].data_ptr())
-        else:
+        elif kind == "dev":
             pipe.submit_depth(d_in.data_ptr(), B, *intr, outs[i].data_ptr())
+        else:
+            if pin_in is None:
+                pin_in = D.pinned_empty(depth.shape, np.uint16)
+                pin_in[:] = depth
+            shape = (B, nvh[0], nvh[1]) if kind == "cells" else (B, H * W)
+            o = np.full(shape, -1, np.int32) if kind == "page" else D.pinned_empty(shape, np.int32)
+            o[...] = -1
+            outs[i] = o
+            pipe.submit_depth_host(depth if kind == "page" else pin_in, *intr, o, cells=(kind == "cells"))
         if rng.random() < 0.2:
             pipe.sync()
     pipe.sync()
     for i in range(nsub):
-        assert np.array_equal(outs[i].cpu().numpy(), ref), f"pipeline submission {i} (slots {slots}, group {group}, nsub {nsub})"
+        got = outs[i].cpu().numpy() if kinds[i] == "dev" or xyz else np.asarray(outs[i])
+        if kinds[i] == "cells" and not xyz:
+            got = ex0.expand_cell_labels(got)
+        assert np.array_equal(got, ref), f"pipeline submission {i} ({kinds[i]}; slots {slots}, group {group}, nsub {nsub})"
     del pipe
 
 
