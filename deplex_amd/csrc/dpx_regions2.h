@@ -164,7 +164,7 @@ __host__ __device__ inline R2Layout r2_layout(int tier, int C, int nb, int nh) {
   }
   L.grow_x = L.image_end;
   L.grow_end = tier == 2 ? L.grow_x  // (tier 2 grows event by event: no scratch)
-                         : L.grow_x + 8u * static_cast<uint32_t>(nb) + (4u << claim_bits(tier)) + kEvBytes + (tier == 0 ? (4u << kRingBits) : 0u);
+                         : L.grow_x + 8u * static_cast<uint32_t>(nb) + (4u << claim_bits(tier)) + kEvBytes + (tier == 0 ? (4u << kRingBits) + 8u * static_cast<uint32_t>(nb) : 0u);
   return L;
 }
 // LDS of the one-wave tier-0 grow launch of the split form
@@ -514,6 +514,17 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
     uint32_t* rres = reinterpret_cast<uint32_t*>(rrec + 64);
     uint8_t* rsrc = reinterpret_cast<uint8_t*>(rres + 64);
     uint32_t* ring = ctab + (1 << kClaimBits) + (kEvBytes >> 2);  // tier 0 only (kEvBytes is a multiple of 4)
+    // Tier 0, single launch: wave 1 — idle otherwise while wave 0 grows — keeps looking for the first live entry of every
+    // bin's list and publishes (list position << 32 | cell) here; wave 0 starts its own search from there.  Sound because
+    // an entry that is dead stays dead: "everything in front of this position is dead" never stops being true, and wave 0
+    // checks the published cell's flag itself before taking it.  One 8-byte word per bin, written by wave 1 only.
+    constexpr bool HELP = GST && PHASE == 0;
+    constexpr uint32_t kHeadNone = 0xFFFFFFFFu;
+    unsigned long long* headpc = reinterpret_cast<unsigned long long*>(ring + (1 << kRingBitsL));
+    // (one 8-byte LDS access each — atomics, so that the compiler cannot split them: a position from one publication with
+    // the cell of another would let wave 0 step over an entry nobody has looked at)
+    auto head_load = [](unsigned long long* a) { return __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto head_store = [](unsigned long long* a, unsigned long long v) { __hip_atomic_store(a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     constexpr uint32_t kRingMask = (1u << kRingBitsL) - 1u;
     auto claim_slot = [&](uint32_t k) { return (k * 2654435761u) >> (32 - kClaimBits); };
     if (TIER != 2 && wid == 0) {
@@ -522,8 +533,11 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
         bclaim[i] = 0xFFFFFFFFu;
       }
       for (int i = lane; i < (1 << kClaimBits); i += 64) ctab[i] = 0xFFFFFFFFu;
+      if constexpr (HELP)
+        for (int i = lane; i < nb; i += 64) headpc[i] = static_cast<unsigned long long>(kHeadNone);  // position 0, no cell
       wave_sync();
     }
+    if constexpr (HELP) __syncthreads();  // (every wave of a tier-0 workgroup is here: wave 1 reads what wave 0 just set up)
     // BFS lane constants: lane = (slot, dir); dir 0..3 = U, D, L, R
     const int slot = lane >> 2, dir = lane & 3;
     const int delta = dir == 0 ? -nh : (dir == 1 ? nh : (dir == 2 ? -1 : 1));
@@ -553,6 +567,61 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
     };
     for (int round = 0;; ++round) {
       int st = 2;  // 2: no further grow, 0: wave 0 finished this grow's BFS (or committed it), 1: wide BFS wanted
+      if (HELP && wid == 1) {
+        // The helper: chunk after chunk of the bin list, one bin per lane — exactly wave 0's seed search (four entries per
+        // lane, then up to two 64-entry steps for lanes that found nothing) — until wave 0 announces the round's barrier
+        // in hdr[42].  It reads bin_start / hist / flags while wave 0 changes them: a stale value only makes it look at
+        // entries that are dead by now, never skip a live one.
+        volatile int* req = hdr + 42;
+        for (int spin = 0; *req != round + 1 && spin < (1 << 16); ++spin) {  // (bounded: a helper that stops helping is harmless)
+          for (int q = 0; q < nsets && *req != round + 1; ++q) {
+            const int t = lane + 64 * q;
+            const int hb = t < nnz ? static_cast<int>(nzlist[t]) : -1;
+            const bool have = hb >= 0 && hist[hb >= 0 ? hb : 0] > 0;
+            const int hbs = have ? hb : 0;
+            const unsigned long long pc = head_load(&headpc[hbs]);
+            const int ppos = static_cast<int>(pc >> 32);
+            const uint32_t pcell = static_cast<uint32_t>(pc);
+            const int bst = static_cast<int>(bin_start[hbs]);
+            const int hend = cursor[hbs];
+            int hpos = ppos > bst ? ppos : bst;
+            const bool cached = pcell != kHeadNone && ppos == hpos;
+            bool hneed = have && hpos < hend && !(cached && (flags[pcell] & F_UNASSIGNED) != 0u);
+            if (hneed && cached) ++hpos;  // the published head died
+            uint32_t hfound = kHeadNone;
+            if (hneed && hpos < hend) {
+              const int i1 = hpos + 1 < hend ? hpos + 1 : hend - 1, i2 = hpos + 2 < hend ? hpos + 2 : hend - 1, i3 = hpos + 3 < hend ? hpos + 3 : hend - 1;
+              const uint32_t e0 = order[hpos], e1 = order[i1], e2 = order[i2], e3 = order[i3];
+              const uint32_t f0 = flags[e0], f1 = flags[e1], f2 = flags[e2], f3 = flags[e3];
+              if (f0 & F_UNASSIGNED) hfound = e0;
+              else if ((f1 & F_UNASSIGNED) && hpos + 1 < hend) { hfound = e1; hpos += 1; }
+              else if ((f2 & F_UNASSIGNED) && hpos + 2 < hend) { hfound = e2; hpos += 2; }
+              else if ((f3 & F_UNASSIGNED) && hpos + 3 < hend) { hfound = e3; hpos += 3; }
+              else hpos = hpos + 4 < hend ? hpos + 4 : hend;
+            }
+            if (hneed) head_store(&headpc[hbs], (static_cast<unsigned long long>(static_cast<uint32_t>(hpos)) << 32) | hfound);
+            unsigned long long hm = __ballot(hneed && hfound == kHeadNone && hpos < hend);
+            for (int it = 0; it < 2 && hm; ++it) {
+              const int l = static_cast<int>(__builtin_ctzll(hm));
+              hm &= hm - 1ull;
+              const int p = __builtin_amdgcn_readlane(hpos, l), e = __builtin_amdgcn_readlane(hend, l), lb = __builtin_amdgcn_readlane(hbs, l);
+              const int i = p + lane;
+              const uint32_t ce = order[i < e ? i : e - 1];
+              const bool alive = i < e && (flags[ce] & F_UNASSIGNED) != 0u;
+              const unsigned long long am = __ballot(alive);
+              int np = p + 64 < e ? p + 64 : e;
+              uint32_t nf = kHeadNone;
+              if (am) {
+                const int first = static_cast<int>(__builtin_ctzll(am));
+                np = p + first;
+                nf = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ce), first));
+              }
+              if (lane == 0) head_store(&headpc[lb], (static_cast<unsigned long long>(static_cast<uint32_t>(np)) << 32) | nf);
+            }
+          }
+          __builtin_amdgcn_s_sleep(8);
+        }
+      }
       if (!GST || wid == 0) {
         // wave 0 runs grow after grow on its own and comes to the barrier below only to ask for a wide BFS or to end
         for (;; ++guard) {
@@ -773,6 +842,10 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
               const int l1 = static_cast<int>(__builtin_ctzll(partmask));
               bb = __builtin_amdgcn_readlane(b, l1);
               int s0 = static_cast<int>(bin_start[bb]);  // (same address in every lane: one LDS broadcast)
+              if constexpr (HELP) {
+                const int hp = static_cast<int>(head_load(&headpc[bb]) >> 32);  // (the helper's position: everything in front of it is dead)
+                s0 = hp > s0 ? hp : s0;
+              }
               const int e1 = cursor[bb];
               bool iso1 = false;
               while (s0 < e1) {
@@ -840,6 +913,22 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
             if (need) {
               if (cw != kCandNone) ++pos;  // the cached entry died (activated by another bin's grow)
               big = false;
+              if constexpr (HELP) {  // what the helper has found for this bin (see headpc)
+                const unsigned long long pc = head_load(&headpc[bs]);
+                const int hp = static_cast<int>(pc >> 32);
+                const uint32_t hc = static_cast<uint32_t>(pc);
+                if (hp >= pos) {
+                  pos = hp;  // everything in front of hp is dead
+                  if (hc != kHeadNone) {
+                    if ((flags[hc] & F_UNASSIGNED) != 0u) {
+                      c = hc;
+                      need = false;
+                    } else {
+                      ++pos;
+                    }
+                  }
+                }
+              }
             }
             bool broken = false;
             const unsigned long long t_s0 = DPX_STAMP();
@@ -1228,6 +1317,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
       }
       if constexpr (GST) {
         int* ctl = hdr + 8 + 4 * (round & 1);  // two sets: a wave may still be reading the previous round's
+        if (HELP && tid == 0) *static_cast<volatile int*>(hdr + 42) = round + 1;  // (the helper leaves its loop and comes to the barrier)
         if (tid == 0) {
           ctl[0] = st;
           ctl[1] = head;
