@@ -48,9 +48,9 @@ def dist_env():
 # latency-bound sequence on one wave, so a stream of batches gains from depth until the chip-wide kernels (plane fit,
 # seed-list sort, tails, label expansion) fill the time: 1280x960 x 256: 101 k / 157 k / 199 k (211 k with the final sweep rounds) / 208 k / 185 k frames/s with
 # 2 / 4 / 8 / 12 / 16 batches in flight; 640x480 x 512: 0.78 M / 1.19 M / 1.48 M / 1.37 M with 2 / 4 / 8 / 16; 3840x2160 x 8:
-# 0.85 k / 1.6 k / 3.0 k (3.7 k with the final sweep rounds) with 2 / 4 / 8 (8 in flight = the 64 frames of configs[4] on this one GPU).
+# 0.85 k / 1.6 k / 3.0 k (3.8 k with the final kernels) with 2 / 4 / 8 (8 in flight = the 64 frames of configs[4] on this one GPU).
 # synth4k64 = ALL 64 frames of configs[4] per step on one GPU (the noisiest frame of a batch sets the batch's time and a frame
-# holds one CU: 64-frame batches keep 256+ frames in flight): 5.8 k / 10.0 k / 12.8 k (13.9 k) frames/s with 2 / 4 / 8 batches in flight.
+# holds one CU: 64-frame batches keep 256+ frames in flight): 5.8 k / 10.0 k / 12.8 k (15.8 k with the final kernels) frames/s with 2 / 4 / 8 batches in flight.
 BIG_WORKLOADS = {"synth1280": dict(batch=256, unique=8, steps=32, warmup=8, streams=8), "synth640": dict(batch=512, unique=16, steps=64, warmup=16, streams=8),
                  "synth4k": dict(batch=8, unique=4, steps=24, warmup=8, streams=8), "synth4k64": dict(batch=64, unique=4, steps=24, warmup=8, streams=8)}
 
