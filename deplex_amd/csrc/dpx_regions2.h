@@ -237,7 +237,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
   unsigned long long t_start = DPX_STAMP(), t_p0 = 0, t_p1 = 0, t_p2 = 0, t_p3 = 0, t_p4 = 0, t_p5 = 0;
   const unsigned long long t_res = (PHASE > 0 && rx.res) ? static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) : 0ull;
   const unsigned long long t_real = ((PHASE == 2 || PHASE == 4) && rx.res) ? static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()) : 0ull;
-  unsigned long long a_argmax = 0, a_seed = 0, a_bfs = 0, n_steps = 0, n_spec = 0, n_rounds = 0, n_scan1 = 0, n_scan64 = 0, a_scan = 0, a_spec = 0, n_pops = 0, n_stop_inc = 0, n_stop_bin = 0, n_stop_cell = 0, a_claims = 0, a_commit = 0, n_fast = 0, a_fast = 0, n_gather = 0, n_itemover = 0;
+  unsigned long long a_argmax = 0, a_seed = 0, a_bfs = 0, n_steps = 0, n_spec = 0, n_rounds = 0, n_scan1 = 0, n_scan64 = 0, a_scan = 0, a_spec = 0, n_pops = 0, n_stop_inc = 0, n_stop_bin = 0, n_stop_cell = 0, a_claims = 0, a_commit = 0, n_fast = 0, a_fast = 0, n_gather = 0, n_itemover = 0, n_cont = 0;
   const int frame = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int C = prm.C, nh = prm.nh, nv = prm.nv;
@@ -544,6 +544,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
     const uint32_t opp = static_cast<uint32_t>(dir ^ 1);
     const uint32_t notme = ~(1u << opp) & 0xFu;
     int guard = 0;  // grows started (wave 0's count; the reference's loop ends by itself, this is a safety net)
+    int cont_b = -1, cont_level = 0;  // the event list of the last arg-max, see "An unfinished sweep" in the round
     int head = 0, gstart = 0;
     bool in_grow = false;
     unsigned long long ta = 0, tb = 0, tc = 0;
@@ -746,6 +747,26 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
             if (seed == 0xFFFFFFFFu) break;
           } else {
             if (DBG) ++n_rounds;
+            // 0. An unfinished sweep goes on without an arg-max: the events of the previous round (cont_b, one bin per lane,
+            // at level cont_level) that neither fired nor lost a cell are still at that level — exactly the bins whose count
+            // still equals it, since a bin only ever loses cells — no bin can have risen above it, and every bin at that
+            // level that the previous list did not hold (it holds at most 64) has a higher index than all it holds.  So the
+            // remaining listed bins, in lane order, are the next events; only when none is left does the maximum have to be
+            // found again.
+            int b = -1, bv = 0, nev = 0;
+            bool part = false;
+            unsigned long long partmask = 0ull;
+            if (cont_level > 0) {  // (uniform)
+              part = cont_b >= 0 && hist[cont_b >= 0 ? cont_b : 0] == cont_level;
+              partmask = __ballot(part);
+              if (partmask) {
+                b = part ? cont_b : -1;
+                bv = cont_level;
+                nev = static_cast<int>(__popcll(partmask));
+                if (DBG) ++n_cont;
+              }
+            }
+            if (!partmask) {
             // 1. level of the most frequent bin, and the first 64-bin chunk that holds a bin at that level
             uint32_t key = 0;
             uint32_t cntq[4] = {0u, 0u, 0u, 0u};  // counts of this lane's bins (chunks 0..3)
@@ -763,7 +784,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
               key = k > key ? k : key;
             }
             key = wave_max_u32(key);
-            const int bv = static_cast<int>(key >> 8);
+            bv = static_cast<int>(key >> 8);
             int qc = 255 - static_cast<int>(key & 255u);
             if (bv <= 0) break;
             if (static_cast<unsigned long long>(bv) < static_cast<unsigned long long>(static_cast<long long>(prm.min_cand))) break;
@@ -773,8 +794,6 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
                 if (__ballot(t < nnz && hist[nzlist[t]] == bv)) break;
               }
             // 2. the events of this round: bins at level bv, ascending = lane order; those of chunk qc first
-            int b;
-            bool part;
             if (qc < 4) {
               b = mybin[0];
               b = qc == 1 ? mybin[1] : b;
@@ -790,8 +809,8 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
               b = t < nnz ? static_cast<int>(nzlist[t]) : -1;
               part = b >= 0 && hist[b >= 0 ? b : 0] == bv;
             }
-            unsigned long long partmask = __ballot(part);
-            int nev = static_cast<int>(__popcll(partmask));
+            partmask = __ballot(part);
+            nev = static_cast<int>(__popcll(partmask));
             // The sweep does not end with the chunk: the bins at level bv of the LATER chunks fire right after these, in the
             // same ascending order.  They are appended (through a 64-entry staging array: event e = lane e) until the round
             // is full — a frame with 300 non-empty bins spreads the 20 events of a typical sweep over five chunks, which
@@ -830,6 +849,9 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
                 partmask = nev == 64 ? ~0ull : ((1ull << nev) - 1ull);
               }
             }
+            cont_b = part ? b : -1;
+            cont_level = bv;
+            }  // (arg-max)
             const int bs = b >= 0 ? b : 0;
             tb = DPX_STAMP();
             if (nev < kSweepMinEvents) {
@@ -1936,7 +1958,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
       d[0] = t_p0 - t_start; d[1] = t_p1 - t_p0; d[2] = t_p2 - t_p1; d[3] = t_p3 - t_p2; d[4] = t_p4 - t_p3;
       d[5] = t_p5 - t_p4; d[6] = t_end - t_p5; d[7] = t_end - t_start;
       d[8] = a_argmax; d[9] = a_seed; d[10] = a_bfs; d[11] = n_rounds | (n_spec << 32); d[12] = n_steps; d[13] = ngrow; d[14] = ncand; d[15] = activations;
-      d[16] = a_scan; d[17] = a_spec; d[18] = n_scan1; d[19] = n_scan64; d[20] = n_pops; d[21] = n_stop_inc; d[22] = n_stop_bin; d[23] = n_stop_cell; d[24] = a_claims; d[25] = a_commit; d[26] = n_fast; d[27] = a_fast; d[28] = n_gather; d[29] = n_itemover;
+      d[16] = a_scan; d[17] = a_spec; d[18] = n_scan1; d[19] = n_scan64; d[20] = n_pops; d[21] = n_stop_inc; d[22] = n_stop_bin; d[23] = n_stop_cell; d[24] = a_claims; d[25] = a_commit; d[26] = n_fast; d[27] = a_fast; d[28] = n_gather; d[29] = n_itemover; d[30] = n_cont;
     }
   }
 }
