@@ -105,6 +105,8 @@ for it in range(cases):
         kw = qk
     else:
         depth = np.stack([synth.synth_depth(h, w, seed=seed + k, **kw) for k in range(B)])
+    if os.environ.get("DPX_FUZZ_VERBOSE"):  # (to find a case that never returns: its parameters are printed first)
+        print(f"case {it}: {h}x{w} P={P} B={B} seed={seed} env={env} xyz={xyz} ov={ov} kw={kw}", flush=True)
     if env:
         os.environ[env] = "1"
     try:
