@@ -237,7 +237,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
   unsigned long long t_start = DPX_STAMP(), t_p0 = 0, t_p1 = 0, t_p2 = 0, t_p3 = 0, t_p4 = 0, t_p5 = 0;
   const unsigned long long t_res = (PHASE > 0 && rx.res) ? static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) : 0ull;
   const unsigned long long t_real = ((PHASE == 2 || PHASE == 4) && rx.res) ? static_cast<unsigned long long>(__builtin_amdgcn_s_memrealtime()) : 0ull;
-  unsigned long long a_argmax = 0, a_seed = 0, a_bfs = 0, n_steps = 0, n_spec = 0, n_rounds = 0, n_scan1 = 0, n_scan64 = 0, a_scan = 0, a_spec = 0, n_pops = 0, n_stop_inc = 0, n_stop_bin = 0, n_stop_cell = 0, a_claims = 0, a_commit = 0, n_fast = 0, a_fast = 0, n_gather = 0, n_itemover = 0, n_cont = 0;
+  unsigned long long a_argmax = 0, a_seed = 0, a_bfs = 0, n_steps = 0, n_spec = 0, n_rounds = 0, n_scan1 = 0, n_scan64 = 0, a_scan = 0, a_spec = 0, n_pops = 0, n_stop_inc = 0, n_stop_bin = 0, n_stop_cell = 0, a_claims = 0, a_commit = 0, n_fast = 0, a_fast = 0, n_gather = 0, n_itemover = 0, n_cont = 0, a_walk = 0;
   const int frame = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int C = prm.C, nh = prm.nh, nv = prm.nv;
@@ -1800,6 +1800,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
         lmerge[i] = i;
       }
     __syncthreads();
+    const unsigned long long t_walk0 = DPX_STAMP();
     if (wid == 0) {
       // bit row for planes with more than 64 adjacency entries (tier 0: global scratch; LDS tiers: behind the views, or
       // the dead queue-position array when there are none)
@@ -1808,7 +1809,51 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
         const int rr = rbase + lane;
         const uint32_t o0 = rr < nplanes ? off[rr] : 0u, o1 = rr < nplanes ? off[rr + 1] : 0u;
         unsigned long long todo = __ballot(o1 > o0);
+        bool one_row = false;  // the next row goes through the one-row path (it has a column to fold)
         while (todo) {
+          // Four rows at a time (plane views in LDS, rows of at most 16 columns): sixteen lanes per row test the row's
+          // columns against the row's CURRENT plane.  Nothing changes while no column is accepted, so if none of the four
+          // rows accepts one — 85 % of the rows of a noisy frame — all four are done; otherwise the rows in front of the
+          // first accepting one are done and that one is walked again on its own below (folds, refit), the later ones
+          // after it.  Same tests on the same state as the sequential walk, row after row.
+          if (views && !one_row) {
+            unsigned long long t2 = todo;
+            int r4[4];
+  #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              r4[j] = t2 ? static_cast<int>(__builtin_ctzll(t2)) : -1;
+              t2 &= t2 - 1ull;  // (0 stays 0)
+            }
+            const int g = lane >> 4, l16 = lane & 15;
+            const int rsel = g == 0 ? r4[0] : (g == 1 ? r4[1] : (g == 2 ? r4[2] : r4[3]));
+            const int src = rsel >= 0 ? rsel : 0;
+            const int gs0 = __shfl(static_cast<int>(o0), src), ge0 = __shfl(static_cast<int>(o1), src);
+            const int gdeg = rsel >= 0 ? ge0 - gs0 : 0;
+            if (!__ballot(gdeg > 16)) {
+              const int grow = rbase + src;
+              const int gpid = lmerge[grow];
+              const float* gv = pview + gpid * 7;
+              const float gnx = gv[0], gny = gv[1], gnz = gv[2], gd = gv[3];
+              bool gacc = false;
+              if (l16 < gdeg) {
+                const uint32_t gcol = cols[gs0 + l16];
+                const float* cv = pview + gcol * 7;
+                gacc = merge_test(gnx, gny, gnz, gd, cv[0], cv[1], cv[2], cv[4], cv[5], cv[6]);
+              }
+              const unsigned long long gm = __ballot(gacc);
+              if (!gm) {
+                todo = t2;  // all (up to) four rows had nothing to fold
+                continue;
+              }
+              const int gstar = static_cast<int>(__builtin_ctzll(gm)) >> 4;
+  #pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (j < gstar) todo &= ~(1ull << r4[j]);  // (r4[j] >= 0 for j < gstar: a group in front of an accepting one is a row)
+              one_row = true;
+              continue;
+            }
+          }
+          one_row = false;
           const int rl = __builtin_ctzll(todo);
           todo &= todo - 1;
           const int row = rbase + rl;
@@ -1898,6 +1943,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      if (DBG) a_walk = DPX_STAMP() - t_walk0;
     }
   }
   if (!solo) __syncthreads();
@@ -1958,7 +2004,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
       d[0] = t_p0 - t_start; d[1] = t_p1 - t_p0; d[2] = t_p2 - t_p1; d[3] = t_p3 - t_p2; d[4] = t_p4 - t_p3;
       d[5] = t_p5 - t_p4; d[6] = t_end - t_p5; d[7] = t_end - t_start;
       d[8] = a_argmax; d[9] = a_seed; d[10] = a_bfs; d[11] = n_rounds | (n_spec << 32); d[12] = n_steps; d[13] = ngrow; d[14] = ncand; d[15] = activations;
-      d[16] = a_scan; d[17] = a_spec; d[18] = n_scan1; d[19] = n_scan64; d[20] = n_pops; d[21] = n_stop_inc; d[22] = n_stop_bin; d[23] = n_stop_cell; d[24] = a_claims; d[25] = a_commit; d[26] = n_fast; d[27] = a_fast; d[28] = n_gather; d[29] = n_itemover; d[30] = n_cont;
+      d[16] = a_scan; d[17] = a_spec; d[18] = n_scan1; d[19] = n_scan64; d[20] = n_pops; d[21] = n_stop_inc; d[22] = n_stop_bin; d[23] = n_stop_cell; d[24] = a_claims; d[25] = a_commit; d[26] = n_fast; d[27] = a_fast; d[28] = n_gather; d[29] = n_itemover; d[30] = n_cont; d[31] = a_walk;
     }
   }
 }

@@ -259,7 +259,8 @@ int64_t dpx_planefit_bytes(dpx_handle h, int32_t input_kind, int32_t batch);
  * by rounds << 32; BFS steps, grows, candidates, activations; [16..20] = cycles in list scans, cycles in speculative
  * grows, per-lane scan steps, 64-entry scan steps, speculative pops; [21..27] = why rounds stopped, cycles in claims /
  * resolution + commit, rounds that took a single event and their cycles; [28] = rounds whose events came from several
- * chunks of the bin list, [29] = grows given up beyond a round's 64th item).  enable != 0 switches the diagnostic
+ * chunks of the bin list, [29] = grows given up beyond a round's 64th item, [30] = rounds that continued a sweep without an
+ * arg-max, [31] = cycles of the CSR merge walk).  enable != 0 switches the diagnostic
  * instantiation on for later calls; never used when timing. */
 int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_t* out24);
 /* Diagnostic (handles created with DPX_RESIDENCY=1 in the environment): average shader-clock lifetime of a frame's

@@ -27,7 +27,7 @@ names = ["P0 load", "P1 seeds+bfs", "P2 accum", "P3 fits", "P4 labels", "P5 merg
          "cyc scans", "cyc spec", "lane scan steps", "wave scan steps", "spec pops",
          "stops: large grow", "stops: bin touched", "stops: cell taken",
          "cyc claims", "cyc resolve+commit", "single-event rounds", "cyc single-event rounds", "rounds with events from several chunks",
-         "grows given up beyond the 64th item", "rounds that continued a sweep without an arg-max"]
+         "grows given up beyond the 64th item", "rounds that continued a sweep without an arg-max", "cyc CSR merge walk (wave 0)"]
 for f in (range(B) if B <= 8 else sorted(set((0, 1, B - 1)))):
     out = np.zeros(32, dtype=np.uint64)
     _capi.check(_capi.lib().dpx_debug_region_phases(ex._h, 1, f, out.ctypes.data))
