@@ -17,6 +17,7 @@
 #include "dpx_planefit_fast.h"
 #include "dpx_regions.h"
 #include "dpx_regions2.h"
+#include "dpx_regions3.h"
 #include "dpx_binsort.h"
 #include "dpx_refine.h"
 #include "dpx_png.h"
@@ -93,6 +94,15 @@ struct dpx_handle_s {
   uint8_t* d_gflags = nullptr;
   uint8_t* d_gowner = nullptr;
   uint32_t* d_gqueue = nullptr;
+  // region growing through cores (dpx_regions3.h): large frames
+  bool cores = false;
+  int core_wb = 0;                            // bitmap words per frame
+  size_t lds3_sim = 0;                        // LDS of the one-wave sequence launch
+  uint32_t* d_core = nullptr;                 // one allocation: parent | csize | cstart | cfill | corecells | cgrow | cellq | worklist | biglist
+  uint32_t *d_parent = nullptr, *d_csize = nullptr, *d_cstart = nullptr, *d_cfill = nullptr, *d_corecells = nullptr, *d_cgrow = nullptr,
+           *d_cellq = nullptr, *d_worklist = nullptr, *d_biglist = nullptr, *d_abits = nullptr, *d_ccursor = nullptr;
+  int* d_order_task = nullptr;
+  unsigned long long* d_order64 = nullptr;    // [B][C] seed lists with each cell's core beside it
   // staging for the host-pointer API (lazy)
   void* d_in = nullptr;
   size_t d_in_bytes = 0;
@@ -146,6 +156,8 @@ void free_all(dpx_handle h) {
   hipFree(h->d_gflags);
   hipFree(h->d_gowner);
   hipFree(h->d_gqueue);
+  hipFree(h->d_core);
+  hipFree(h->d_order64);
   hipFree(h->d_sort_keys);
   hipFree(h->d_bin_off);
   hipFree(h->d_gqpos);
@@ -344,6 +356,15 @@ struct SubBatch {
   bool fd_ok;            // the reciprocal division is exact for this geometry (else IEEE division)
 };
 
+dpx::CoreBufs core_bufs(dpx_handle h) {
+  dpx::CoreBufs cb{};
+  cb.meta = h->d_meta; cb.parent = h->d_parent; cb.csize = h->d_csize; cb.cstart = h->d_cstart; cb.cfill = h->d_cfill;
+  cb.corecells = h->d_corecells; cb.cgrow = h->d_cgrow; cb.abits = h->d_abits; cb.cursor = h->d_ccursor; cb.cellq = h->d_cellq;
+  cb.order_task = h->d_order_task;
+  cb.Wb = h->core_wb;
+  return cb;
+}
+
 // seed lists of the sorted region tiers (dpx_binsort.h): keys -> bitonic network -> per-bin cell lists
 void launch_binsort(dpx_handle h, const dpx::Params& prm, hipStream_t s) {
   const int Cpad = h->Cpad, B = prm.batch;
@@ -359,7 +380,11 @@ void launch_binsort(dpx_handle h, const dpx::Params& prm, hipStream_t s) {
       hipLaunchKernelGGL(dpx::k_sort_global, dim3(static_cast<unsigned>((slots / 2 + 255) / 256)), dim3(256), 0, s, h->d_sort_keys, Cpad, B, j, k);
     hipLaunchKernelGGL(dpx::k_sort_tile, dim3(tiles), dim3(dpx::kSortThreads), lds, s, h->d_sort_keys, Cpad, tile, k);
   }
-  hipLaunchKernelGGL(dpx::k_sort_lists, dim3(g256), dim3(256), 0, s, prm, h->d_sort_keys, Cpad, h->d_order, h->d_bin_off);
+  if (h->cores) {
+    hipLaunchKernelGGL(dpx::k_sort_lists64, dim3(g256), dim3(256), 0, s, prm, h->d_sort_keys, Cpad, core_bufs(h), h->d_order64, h->d_bin_off);
+  } else {
+    hipLaunchKernelGGL(dpx::k_sort_lists, dim3(g256), dim3(256), 0, s, prm, h->d_sort_keys, Cpad, h->d_order, h->d_bin_off);
+  }
 }
 
 int fill_sub(dpx_handle h, SubBatch& sb, const void* d_in, int32_t* d_labels, bool depth, float fx, float fy, float cx, float cy) {
@@ -457,6 +482,15 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   const long long total = static_cast<long long>(batch) * prm.C;
   if (total > 0 && h->regions_tier != 2)
     hipLaunchKernelGGL(dpx::k_cellgraph, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, prm, h->d_cells, h->d_meta, h->d_mse_c);
+  const dim3 cell_grid(static_cast<unsigned>((prm.C + 255) / 256), static_cast<unsigned>(batch));
+  if (total > 0 && h->cores && !skip_r) {  // cores of the symmetric edges (dpx_regions3.h), before the seed lists that carry them
+    const dpx::CoreBufs cb = core_bufs(h);
+    hipLaunchKernelGGL(dpx::k_core_init, cell_grid, dim3(256), 0, s, prm, cb);
+    hipLaunchKernelGGL(dpx::k_core_link, cell_grid, dim3(256), 0, s, prm, cb);
+    hipLaunchKernelGGL(dpx::k_core_flatten, cell_grid, dim3(256), 0, s, prm, cb);
+    hipLaunchKernelGGL(dpx::k_core_alloc, cell_grid, dim3(256), 0, s, prm, cb);
+    hipLaunchKernelGGL(dpx::k_core_scatter, cell_grid, dim3(256), 0, s, prm, cb);
+  }
   if (total > 0 && (h->regions_tier == 1 || h->regions_tier == 0) && !skip_r) launch_binsort(h, prm, s);
   if (prof) DPX_HIP(hipEventRecord(ev[3], s));
   dpx::RegionBufs rb{};
@@ -477,6 +511,26 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   rx.frames_per_out = per_sub;
   for (int j = 0; j < dpx::kMaxGroup; ++j) rx.labels_out[j] = (fuse_labels && j < nsub) ? subs[j].d_labels : nullptr;
   if (skip_r) {
+  } else if (h->cores) {
+    if (total > 0) {
+      dpx::SimBufs sb{};
+      sb.order64 = h->d_order64; sb.bin_off = h->d_bin_off; sb.abits0 = h->d_abits; sb.corecells = h->d_corecells; sb.meta = h->d_meta;
+      sb.parent = h->d_parent; sb.csize = h->d_csize; sb.cstart = h->d_cstart; sb.cgrow = h->d_cgrow; sb.worklist = h->d_worklist;
+      sb.cand_grow = reinterpret_cast<uint4*>(h->d_cand_grow); sb.biglist = h->d_biglist;
+      sb.hdr_out = reinterpret_cast<int*>(h->d_lds_img); sb.pcap = h->pcap; sb.Wb = h->core_wb;
+      sb.dbg = h->d_dbg ? h->d_dbg + static_cast<size_t>(h->max_batch) * dpx::kDbgSlots : nullptr;
+      dpx::OrderBufs ob{};
+      ob.cellq = h->d_cellq; ob.cand_grow = reinterpret_cast<const uint4*>(h->d_cand_grow); ob.biglist = h->d_biglist;
+      ob.hdr = reinterpret_cast<const int*>(h->d_lds_img); ob.queue = h->d_gqueue; ob.task = h->d_order_task; ob.pcap = h->pcap;
+      ob.dbg = sb.dbg;
+      const int per_frame = std::max(1, std::min(16, 512 / std::max(1, batch)));
+      if (h->d_dbg) hipLaunchKernelGGL(dpx::k_regsim<true>, dim3(batch), dim3(64), h->lds3_sim, s, prm, sb);
+      else hipLaunchKernelGGL(dpx::k_regsim<false>, dim3(batch), dim3(64), h->lds3_sim, s, prm, sb);
+      hipLaunchKernelGGL(dpx::k_cellgrow, cell_grid, dim3(256), 0, s, prm, core_bufs(h));
+      hipLaunchKernelGGL(dpx::k_order<false>, dim3(per_frame, batch), dim3(dpx::kOrderWaves * 64), 0, s, prm, ob);
+      if (h->d_dbg) hipLaunchKernelGGL((dpx::k_regions2<0, true, 3>), dim3(batch), dim3(dpx::kTailRT), h->lds2_p3, s, prm, rb, rx);
+      else hipLaunchKernelGGL((dpx::k_regions2<0, false, 3>), dim3(batch), dim3(dpx::kTailRT), h->lds2_p3, s, prm, rb, rx);
+    }
   } else if (h->regions_tier == 0 && h->tier0_split && !h->d_dbg) {
     hipLaunchKernelGGL((dpx::k_regions2<0, false, 1>), dim3(batch), dim3(dpx::kRT), h->lds2_p1, s, prm, rb, rx);
     hipLaunchKernelGGL((dpx::k_regions2<0, false, 2>), dim3(batch), dim3(64), h->lds2_p2, s, prm, rb, rx);
@@ -925,6 +979,33 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
         h->lds2_bytes = std::max<size_t>(l0.tail_end, l0.grow_end);
       }
     }
+    // Frames beyond tier 2 grow their regions through CORES (dpx_regions3.h): cores + sequence + order launches, then the
+    // tier-0 tail.  DPX_REGIONS_CORES=1 forces the path for any frame that fits it (tests on small frames), the switches that
+    // name one of the cell-level tiers (DPX_REGIONS_LEAN / _GSTATE / _GSPLIT / _V1, DPX_REGIONS_V2=1) keep those as cross-checks.
+    {
+      const char* fc = std::getenv("DPX_REGIONS_CORES");
+      const char* v2 = std::getenv("DPX_REGIONS_V2");
+      const char* gsplit = std::getenv("DPX_REGIONS_GSPLIT");
+      const bool force_cores = fc && fc[0] == '1';
+      const bool named_old = (v1 && v1[0] == '1') || want_lean || want_gst || (gsplit && gsplit[0] == '1') || (v2 && v2[0] == '1') || (force && force[0] == '1');
+      const int Ci = static_cast<int>(C), nbi = static_cast<int>(nb);
+      const dpx::R2Layout l0 = dpx::r2_layout(0, Ci, nbi, nh);
+      const int wb = 2 * ((Ci + 63) / 64);
+      const bool fits_cores = nb < 4600 && C >= 1 && C < (size_t(1) << dpx::kKeyCellBits) && l0.tail_end <= kLdsLimit &&
+                              dpx::s3_layout(nbi, wb).end <= kLdsLimit;
+      if (fits_cores && (force_cores || (!named_old && h->regions_tier != 2))) {
+        h->cores = true;
+        h->core_wb = wb;
+        h->lds3_sim = dpx::s3_layout(nbi, wb).end;
+        h->regions_tier = 0;
+        h->tier0_split = false;
+        h->sort_pad = 0;
+        h->lds2_img = 192;  // what the tail launch takes over from the sequence launch: the header
+        h->lds2_p1 = h->lds2_p2 = h->lds2_p4 = 0;
+        h->lds2_p3 = l0.tail_end;
+        h->lds2_bytes = l0.tail_end;
+      }
+    }
     if (h->regions_tier == 1 || h->regions_tier == 0) {
       h->Cpad = 1;
       while (static_cast<size_t>(h->Cpad) < C) h->Cpad <<= 1;
@@ -955,8 +1036,28 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
     A(dev_alloc(&h->d_bin_off, B * static_cast<size_t>(nb + 1)));
   }
   if (h->regions_tier == 0) {
-    A(dev_alloc(&h->d_gqpos, B * C));
+    A(dev_alloc(&h->d_gqpos, B * C));  // (the core path's tail still uses it: bit row of the merge walk's wide rows)
     A(dev_alloc(&h->d_gqueue, B * C));
+  }
+  if (h->cores) {
+    const size_t wbs = static_cast<size_t>(h->core_wb);
+    A(dev_alloc(&h->d_core, B * (9 * C + wbs + 2)));
+    A(dev_alloc(&h->d_order64, B * C));
+    if (rc == DPX_OK) {
+      uint32_t* q = h->d_core;
+      h->d_parent = q; q += B * C;
+      h->d_csize = q; q += B * C;
+      h->d_cstart = q; q += B * C;
+      h->d_cfill = q; q += B * C;
+      h->d_corecells = q; q += B * C;
+      h->d_cgrow = q; q += B * C;
+      h->d_cellq = q; q += B * C;
+      h->d_worklist = q; q += B * C;
+      h->d_biglist = q; q += B * C;
+      h->d_abits = q; q += B * wbs;
+      h->d_ccursor = q; q += B;
+      h->d_order_task = reinterpret_cast<int*>(q);
+    }
   }
   if (std::getenv("DPX_RESIDENCY")) {
     A(dev_alloc(&h->d_res, B * 4));
@@ -993,9 +1094,14 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
           rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
     }
   }
-  if (rc == DPX_OK && (h->regions_tier == 2 || h->regions_tier == 1 || h->tier0_split)) {
+  if (rc == DPX_OK && h->cores && h->lds3_sim > 48 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regsim<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds3_sim)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regsim<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds3_sim)) != hipSuccess)
+      rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
+  }
+  if (rc == DPX_OK && (h->regions_tier == 2 || h->regions_tier == 1 || h->tier0_split || h->cores)) {
     const char* nosplit = std::getenv("DPX_REGIONS_NOSPLIT");
-    h->regions_split = h->tier0_split || !(nosplit && nosplit[0] == '1');
+    h->regions_split = h->tier0_split || h->cores || !(nosplit && nosplit[0] == '1');
     if (h->regions_split) {
       A(dev_alloc(&h->d_lds_img, B * (h->lds2_img / 16)));
       const void* fns[3];
@@ -1305,13 +1411,40 @@ int dpx_prepare_intrinsics(dpx_handle h, float fx, float fy, float cx, float cy,
   return rc;
 }
 
+int dpx_get_options(dpx_handle h, char* buf, int32_t cap) {
+  if (!h || !buf || cap < 1) return fail(DPX_ERR_ARG, "null argument");
+  std::string o = "regions=";
+  o += h->cores ? "cores" : (h->regions_tier == 2 ? "tier2" : (h->regions_tier == 1 ? "tier1" : (h->regions_tier == 0 ? (h->tier0_split ? "tier0-split" : "tier0") : "v1")));
+  o += std::string(";split=") + (h->regions_split ? "1" : "0") + ";stream=" + (h->stream_mode ? "1" : "0");
+  o += std::string(";prep_grow_fused=") + (h->opt_prep_grow_fused ? "1" : "0") + ";fused_labels=" + (h->opt_nofuse ? "0" : "1");
+  o += std::string(";labels_v1=") + (h->opt_labels_v1 ? "1" : "0") + ";cloud_lds=" + (h->opt_cloud_nolds ? "0" : "1") + ";prep_v1=" + (h->opt_prep_v1 ? "1" : "0");
+  o += ";csr_chunk=" + std::to_string(h->opt_csr_chunk) + ";cells=" + std::to_string(h->prm.C) + ";pcap=" + std::to_string(h->pcap);
+  const int n = static_cast<int>(std::min<size_t>(o.size(), static_cast<size_t>(cap) - 1));
+  std::memcpy(buf, o.data(), static_cast<size_t>(n));
+  buf[n] = 0;
+  return n;
+}
+
+int dpx_debug_cores_phases(dpx_handle h, int32_t frame, uint64_t* out32) {
+  if (!h || !out32) return fail(DPX_ERR_ARG, "null argument");
+  if (!h->d_dbg || !h->cores || frame < 0 || frame >= h->max_batch) return fail(DPX_ERR_ARG, "diagnostics not enabled, not the core path, or bad frame");
+  DPX_HIP(hipSetDevice(h->device));
+  DPX_HIP(hipStreamSynchronize(h->last_stream));
+  DPX_HIP(hipMemcpy(out32, h->d_dbg + (static_cast<size_t>(h->max_batch) + frame) * dpx::kDbgSlots, dpx::kDbgSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return DPX_OK;
+}
+
 int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_t* out24) {
   if (!h) return fail(DPX_ERR_ARG, "null handle");
   DPX_HIP(hipSetDevice(h->device));
   if (enable && !h->d_dbg) {
-    DPX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_dbg), static_cast<size_t>(h->max_batch) * dpx::kDbgSlots * sizeof(unsigned long long)));
-    DPX_HIP(hipMemset(h->d_dbg, 0, static_cast<size_t>(h->max_batch) * dpx::kDbgSlots * sizeof(unsigned long long)));
-    if (h->lds2_bytes > 48 * 1024 && h->regions_tier >= 0) {
+    // (two blocks of kDbgSlots words per frame: the k_regions2 stamps, then those of the core path's sequence / order launches)
+    DPX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_dbg), static_cast<size_t>(h->max_batch) * 2 * dpx::kDbgSlots * sizeof(unsigned long long)));
+    DPX_HIP(hipMemset(h->d_dbg, 0, static_cast<size_t>(h->max_batch) * 2 * dpx::kDbgSlots * sizeof(unsigned long long)));
+    if (h->cores) {
+      if (h->lds2_p3 > 48 * 1024)
+        DPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<0, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds2_p3)));
+    } else if (h->lds2_bytes > 48 * 1024 && h->regions_tier >= 0) {
       const void* fn = h->regions_tier == 2   ? reinterpret_cast<const void*>(dpx::k_regions2<2, true, 0>)
                        : h->regions_tier == 1 ? reinterpret_cast<const void*>(dpx::k_regions2<1, true, 0>)
                                               : reinterpret_cast<const void*>(dpx::k_regions2<0, true, 0>);

@@ -1,0 +1,867 @@
+// dpx_regions3.h — region growing for large frames through CORES (round 4).
+//
+// The reference's loop (plane_extractor.cpp:297-347) takes the most frequent histogram bin, grows a region from the
+// bin's minimum-MSE cell with a FIFO BFS over the unassigned cells (growSeed, :349-392), removes the grown cells from
+// the histogram and repeats.  growSeed's accept test reads only static per-cell data besides the unassigned mask, so the
+// cells a grow activates are exactly the cells REACHABLE from its seed in the static directed graph G (edge u -> v iff v
+// accepts u) restricted to the unassigned cells; only their ORDER depends on the FIFO discipline, and the order is read by
+// nothing but the float accumulation of segments that survive the size test (:318-323, :329).
+//
+// Almost every edge of G is symmetric (both directions pass: the cosine is symmetric, the distance test nearly so).  A CORE
+// is a connected component of the symmetric edges.  A core is strongly connected, so a grow takes cores whole: the cells
+// of a grow from seed s are the cores reachable from core(s) over the remaining one-way edges among the cores still alive
+// — and with no one-way edge leaving core(s), simply core(s), whatever happened before.  (Removing a reachable set never
+// splits a core: the unassigned set stays a union of whole cores, by induction.)  Hence:
+//   k_core_*    cores by parallel union-find over the symmetric edges, chip-wide; cells grouped by core (CSR);
+//   k_regsim    the SEQUENCE of grows, one wave per frame: which bin fires, its seed, the cores it takes, the histogram
+//               update — no BFS.  Up to 64 bins of one histogram level fire per round ("sweep rounds", as in
+//               dpx_regions2.h, where the argument for their order is spelled out), validated through per-bin claims;
+//   k_cellgrow  per cell: the grow that took it + its in-edge bits in one word;
+//   k_order     the FIFO activation order of every grow that is a segment candidate, all grows in parallel (wave per
+//               grow; grows of up to 8 cells one LANE each), written to the queue ranges the sequence assigned;
+//   the tail (segment sums in queue order, f64 fits, labels_map_, plane merging) is k_regions2<0, ., 3>.
+// Bit-exact with the cell-level kernels of dpx_regions2.h / the oracle on every record (tests, tools/fuzz_parity.py).
+#pragma once
+#include "dpx_regions2.h"
+
+namespace dpx {
+
+constexpr uint32_t kCoreOut = 0x80000000u;     // csize[root]: a one-way edge leaves this core
+constexpr uint32_t kCoreSizeMask = 0x000FFFFFu;
+constexpr int kCellBits = kKeyCellBits;        // 19: C < 2^19
+constexpr uint32_t kCellMask = (1u << kCellBits) - 1u;
+// seed-list entry (order64): cell | core start << 19 | core size << 38 | one-way-out << 58
+constexpr int kE64StartShift = kCellBits, kE64SizeShift = 2 * kCellBits, kE64OutShift = 2 * kCellBits + 20;
+constexpr int kItemMax = 8;  // cores of up to this many cells are handled inside a sweep round (one item per cell)
+
+struct CoreBufs {
+  const uint32_t* meta;  // [B][C]   k_cellgraph
+  uint32_t* parent;      // [B][C]   union-find forest; after k_core_flatten: the core's root (its lowest cell id)
+  uint32_t* csize;       // [B][C]   at the root: cells of the core | kCoreOut
+  uint32_t* cstart;      // [B][C]   at the root: first slot of the core in corecells
+  uint32_t* cfill;       // [B][C]   at the root: scatter cursor
+  uint32_t* corecells;   // [B][C]   cells grouped by core: cell | (bin + 1) << 19
+  uint32_t* cgrow;       // [B][C]   indexed by core start: grow index + 1 (k_regsim)
+  uint32_t* abits;       // [B][Wb]  planar bitmap (bit c of the frame)
+  uint32_t* cursor;      // [B]      allocation cursor of corecells
+  uint32_t* cellq;       // [B][C]   k_cellgrow: (grow + 1) << 4 | in-edge bits
+  int* order_task;       // [B]      task counter of k_order
+  int Wb;                // bitmap words per frame (even)
+};
+
+__device__ __forceinline__ uint32_t cc_load(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// root of x; pointers only ever move to lower ids, so a stale read is an older ancestor and the chase still ends
+__device__ __forceinline__ uint32_t cc_find(uint32_t* p, uint32_t x) {
+  uint32_t r = x;
+  for (;;) {
+    const uint32_t q = cc_load(p + r);
+    if (q == r) break;
+    r = q;
+  }
+  while (x != r) {  // compression (atomicMin: never undoes a link made meanwhile)
+    const uint32_t nx = cc_load(p + x);
+    if (nx > r) atomicMin(p + x, r);
+    x = nx < x ? nx : r;
+  }
+  return r;
+}
+__device__ __forceinline__ void cc_union(uint32_t* p, uint32_t a, uint32_t b) {
+  for (;;) {
+    a = cc_find(p, a);
+    b = cc_find(p, b);
+    if (a == b) return;
+    if (a < b) {
+      const uint32_t t = a;
+      a = b;
+      b = t;
+    }
+    const uint32_t old = atomicMin(p + a, b);  // link the higher root under the lower one
+    if (old == a) return;
+    a = old;  // a was no longer a root: its tree (now under min(old, b)) still has to meet b's
+  }
+}
+
+// grid (ceil(C / 256), B), 256 threads: thread = cell
+__global__ __launch_bounds__(256) void k_core_init(Params prm, CoreBufs cb) {
+  const int frame = blockIdx.y;
+  const int c = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
+  const size_t fo = static_cast<size_t>(frame) * prm.C;
+  bool planar = false;
+  if (c < prm.C) {
+    planar = (cb.meta[fo + c] & F_UNASSIGNED) != 0u;
+    cb.parent[fo + c] = static_cast<uint32_t>(c);
+    cb.csize[fo + c] = 0u;
+    cb.cfill[fo + c] = 0u;
+    cb.cgrow[fo + c] = 0u;
+  }
+  const unsigned long long m = __ballot(planar);
+  const int w = c >> 5;  // (a wave covers 64 consecutive cells of one frame: two bitmap words)
+  if ((threadIdx.x & 63) == 0 && w < cb.Wb) {
+    uint32_t* ab = cb.abits + static_cast<size_t>(frame) * cb.Wb;
+    ab[w] = static_cast<uint32_t>(m);
+    if (w + 1 < cb.Wb) ab[w + 1] = static_cast<uint32_t>(m >> 32);
+  }
+  if (c == 0) {
+    cb.cursor[frame] = 0u;
+    cb.order_task[frame] = 0;
+  }
+}
+
+// symmetric edge to the right / lower neighbour -> one union
+__global__ __launch_bounds__(256) void k_core_link(Params prm, CoreBufs cb) {
+  const int frame = blockIdx.y;
+  const int c = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
+  if (c >= prm.C) return;
+  const size_t fo = static_cast<size_t>(frame) * prm.C;
+  const uint32_t m = cb.meta[fo + c];
+  if (!(m & F_UNASSIGNED)) return;
+  const uint32_t sym = ((m >> 2) & (m >> 8)) & 0xFu;  // out-edge and in-edge: dir 0..3 = U, D, L, R
+  uint32_t* p = cb.parent + fo;
+  if (sym & 8u) cc_union(p, static_cast<uint32_t>(c), static_cast<uint32_t>(c + 1));
+  if (sym & 2u) cc_union(p, static_cast<uint32_t>(c), static_cast<uint32_t>(c + prm.nh));
+}
+
+// root of every cell, core sizes, "a one-way edge leaves this core"
+__global__ __launch_bounds__(256) void k_core_flatten(Params prm, CoreBufs cb) {
+  const int frame = blockIdx.y;
+  const int c = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
+  if (c >= prm.C) return;
+  const size_t fo = static_cast<size_t>(frame) * prm.C;
+  const uint32_t m = cb.meta[fo + c];
+  if (!(m & F_UNASSIGNED)) return;
+  uint32_t* p = cb.parent + fo;
+  const uint32_t r = cc_find(p, static_cast<uint32_t>(c));
+  atomicAdd(cb.csize + fo + r, 1u);
+  const uint32_t ow = ((m >> 2) & ~(m >> 8)) & 0xFu;  // one-way out-edges
+  if (ow) {
+    bool leaves = false;
+#pragma unroll
+    for (int dir = 0; dir < 4; ++dir)
+      if ((ow >> dir) & 1u) {
+        const int v = c + (dir == 0 ? -prm.nh : (dir == 1 ? prm.nh : (dir == 2 ? -1 : 1)));
+        if (cc_find(p, static_cast<uint32_t>(v)) != r) leaves = true;
+      }
+    if (leaves) atomicOr(cb.csize + fo + r, kCoreOut);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_core_alloc(Params prm, CoreBufs cb) {
+  const int frame = blockIdx.y;
+  const int c = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
+  if (c >= prm.C) return;
+  const size_t fo = static_cast<size_t>(frame) * prm.C;
+  const uint32_t sz = cb.csize[fo + c] & kCoreSizeMask;
+  if (sz == 0u) return;  // (only roots of planar cores have a size)
+  // (after k_core_flatten a cell's parent may still be an intermediate ancestor: its root is found again where needed)
+  cb.cstart[fo + c] = atomicAdd(cb.cursor + frame, sz);
+}
+
+__global__ __launch_bounds__(256) void k_core_scatter(Params prm, CoreBufs cb) {
+  const int frame = blockIdx.y;
+  const int c = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
+  if (c >= prm.C) return;
+  const size_t fo = static_cast<size_t>(frame) * prm.C;
+  const uint32_t m = cb.meta[fo + c];
+  if (!(m & F_UNASSIGNED)) return;
+  const uint32_t r = cc_find(cb.parent + fo, static_cast<uint32_t>(c));
+  cb.parent[fo + c] = r;  // (every cell's own entry: its root, final)
+  const uint32_t pos = cb.cstart[fo + r] + atomicAdd(cb.cfill + fo + r, 1u);
+  cb.corecells[fo + pos] = static_cast<uint32_t>(c) | ((m >> META_BIN_SHIFT) << kCellBits);
+}
+
+// sorted keys (dpx_binsort.h) -> order64[B][C]: the seed lists with each cell's core (start, size, one-way-out) beside
+// it, and bin_off[B][nb + 1] as k_sort_lists writes them
+__global__ __launch_bounds__(256) void k_sort_lists64(Params prm, const unsigned long long* __restrict__ keys, int Cpad, CoreBufs cb,
+                                                      unsigned long long* __restrict__ order64, uint32_t* __restrict__ bin_off) {
+  const long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  const long long total = static_cast<long long>(prm.batch) * Cpad;
+  if (i >= total) return;
+  const int nb = prm.hist_B * prm.hist_B;
+  const int frame = static_cast<int>(i / Cpad), pos = static_cast<int>(i - static_cast<long long>(frame) * Cpad);
+  const unsigned long long key = keys[i];
+  const unsigned long long prev = pos > 0 ? keys[i - 1] : 0ull;
+  const int b = key == ~0ull ? nb : static_cast<int>(key >> kKeyBinShift);
+  const int pb = pos == 0 ? -1 : (prev == ~0ull ? nb : static_cast<int>(prev >> kKeyBinShift));
+  uint32_t* bo = bin_off + static_cast<size_t>(frame) * (nb + 1);
+  for (int x = pb + 1; x <= b && x <= nb; ++x) bo[x] = static_cast<uint32_t>(pos);
+  if (pos == Cpad - 1 && b < nb)
+    for (int x = b + 1; x <= nb; ++x) bo[x] = static_cast<uint32_t>(Cpad);
+  if (key != ~0ull && pos < prm.C) {
+    const size_t fo = static_cast<size_t>(frame) * prm.C;
+    const uint32_t cell = static_cast<uint32_t>(key & kCellMask);
+    const uint32_t r = cb.parent[fo + cell];
+    const uint32_t sz = cb.csize[fo + r], st = cb.cstart[fo + r];
+    order64[fo + pos] = static_cast<unsigned long long>(cell) | (static_cast<unsigned long long>(st) << kE64StartShift) |
+                        (static_cast<unsigned long long>(sz & kCoreSizeMask) << kE64SizeShift) |
+                        (static_cast<unsigned long long>(sz >> 31) << kE64OutShift);
+  }
+}
+
+// ---- the sequence of grows --------------------------------------------------------------------------------------------
+struct SimBufs {
+  const unsigned long long* order64;  // [B][C]
+  const uint32_t* bin_off;            // [B][nb + 1]
+  const uint32_t* abits0;             // [B][Wb]
+  const uint32_t* corecells;          // [B][C]
+  const uint32_t* meta;               // [B][C]  (one-way edges of irregular grows)
+  const uint32_t* parent;             // [B][C]
+  const uint32_t* csize;
+  const uint32_t* cstart;
+  uint32_t* cgrow;                    // [B][C]  by core start: grow + 1
+  uint32_t* worklist;                 // [B][C]  cores of an irregular grow (roots)
+  uint4* cand_grow;                   // [B][pcap]  grow index, queue range [y, z), seed | kCandWide
+  uint32_t* biglist;                  // [B][pcap]  candidate indices of the grows k_order gives a whole wave
+  int* hdr_out;                       // [B][48] the header the tail launch starts from (k_regions2 hdr[] layout) + counts
+  unsigned long long* dbg;            // diagnostic: [B][kDbgSlots]
+  int pcap, Wb;
+};
+constexpr uint32_t kCandWide = 0x80000000u;  // cand_grow.w: the grow is ordered by a whole wave (it is in biglist)
+// hdr_out words: 0 planar cells, 1 activations (queue tail), 2 grows, 3 candidates, 4 entries of biglist
+constexpr int kHdrBig = 4;
+
+struct S3Layout {
+  uint32_t hist, cursor, bin_start, cand, bclaim, nzlist, evb, rrec, rsrc, abits, end;
+};
+__host__ __device__ inline S3Layout s3_layout(int nb, int Wb) {
+  S3Layout L{};
+  uint32_t o = 256;  // header words
+  L.hist = o; o += 4u * nb;
+  L.cursor = o; o += 4u * nb;
+  L.bin_start = o; o += 4u * (nb + 2);
+  o = (o + 7u) & ~7u;
+  L.cand = o; o += 8u * nb;
+  L.bclaim = o; o += 4u * nb;
+  L.nzlist = o; o += 2u * nb;
+  o = (o + 7u) & ~7u;
+  L.evb = o; o += 128;
+  L.rrec = o; o += 64 * 8;
+  L.rsrc = o; o += 64;
+  L.abits = o; o += 4u * static_cast<uint32_t>(Wb);
+  L.end = (o + 15u) & ~15u;
+  return L;
+}
+
+template <bool DBG>
+__global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
+  WaveTrace trace_(TK_GROW);
+#if DPX_REGIONS_PRIO
+  __builtin_amdgcn_s_setprio(DPX_REGIONS_PRIO);
+#endif
+  const unsigned long long t_start = DBG ? static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) : 0ull;
+  unsigned long long n_rounds = 0, n_wide = 0, n_irreg = 0, n_scan64 = 0, n_multi = 0, n_skip = 0;
+  const int frame = blockIdx.x, lane = threadIdx.x;
+  const int C = prm.C, nh = prm.nh;
+  const int nb = prm.hist_B * prm.hist_B;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const S3Layout lay = s3_layout(nb, sb.Wb);
+  int* hdr = reinterpret_cast<int*>(smem);
+  int* hist = reinterpret_cast<int*>(smem + lay.hist);
+  int* cursor = reinterpret_cast<int*>(smem + lay.cursor);          // END of bin b's list
+  uint32_t* bin_start = reinterpret_cast<uint32_t*>(smem + lay.bin_start);  // first possibly live entry
+  unsigned long long* candc = reinterpret_cast<unsigned long long*>(smem + lay.cand);  // verified head entry of the bin's list
+  uint32_t* bclaim = reinterpret_cast<uint32_t*>(smem + lay.bclaim);
+  uint16_t* nzlist = reinterpret_cast<uint16_t*>(smem + lay.nzlist);
+  uint16_t* evb = reinterpret_cast<uint16_t*>(smem + lay.evb);
+  uint2* rrec = reinterpret_cast<uint2*>(smem + lay.rrec);
+  uint8_t* rsrc = smem + lay.rsrc;
+  uint32_t* abits = reinterpret_cast<uint32_t*>(smem + lay.abits);
+
+  const size_t fo = static_cast<size_t>(frame) * C;
+  const unsigned long long* order = sb.order64 + fo;
+  const uint32_t* corecells = sb.corecells + fo;
+  uint32_t* cgrow = sb.cgrow + fo;
+  uint4* cand_grow = sb.cand_grow + static_cast<size_t>(frame) * sb.pcap;
+  uint32_t* biglist = sb.biglist + static_cast<size_t>(frame) * sb.pcap;
+  constexpr unsigned long long kNone = ~0ull;
+
+  // ---- state: histogram and list bounds from the sorted seed lists, planar bitmap, non-empty bins
+  if (lane < 64) hdr[lane] = 0;
+  {
+    const uint32_t* bo = sb.bin_off + static_cast<size_t>(frame) * (nb + 1);
+    for (int b = lane; b < nb; b += 64) {
+      const uint32_t s0 = bo[b], s1 = bo[b + 1];
+      hist[b] = static_cast<int>(s1 - s0);
+      bin_start[b] = s0;
+      cursor[b] = static_cast<int>(s1);
+      candc[b] = kNone;
+      bclaim[b] = 0xFFFFFFFFu;
+    }
+  }
+  int planar_cnt = 0;
+  {
+    const uint32_t* a0 = sb.abits0 + static_cast<size_t>(frame) * sb.Wb;
+    for (int w = lane; w < sb.Wb; w += 64) {
+      const uint32_t v = a0[w];
+      abits[w] = v;
+      planar_cnt += __popc(v);
+    }
+  }
+  const int planar_total = wave_sum(planar_cnt);
+  wave_sync();
+  {
+    int nz = 0;
+    for (int base = 0; base < nb; base += 64) {
+      const int b = base + lane;
+      const int v = b < nb ? hist[b] : 0;
+      const unsigned long long nzm = __ballot(v > 0);
+      if (v > 0) nzlist[nz + __popcll(nzm & lt_mask)] = static_cast<uint16_t>(b);
+      nz += static_cast<int>(__popcll(nzm));
+    }
+    if (lane == 0) hdr[5] = nz;
+  }
+  wave_sync();
+  auto alive = [&](uint32_t cell) { return ((abits[cell >> 5] >> (cell & 31u)) & 1u) != 0u; };
+  auto kill = [&](uint32_t cell) { atomicAnd(&abits[cell >> 5], ~(1u << (cell & 31u))); };
+
+  int remaining = planar_total;
+  int tail = 0, ngrow = 0, ncand = 0, nbig = 0;
+  const int nnz = hdr[5];
+  int mybin[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) mybin[q] = (lane + 64 * q < nnz) ? static_cast<int>(nzlist[lane + 64 * q]) : -1;
+  const int nsets = (nnz + 63) >> 6;
+  int cont_b = -1, cont_level = 0;
+  for (int guard = 0; remaining > 0 && guard <= C; ++guard) {
+    if (DBG) ++n_rounds;
+    // ---- the events of this round: the bins at the histogram's maximum, ascending = lane order (dpx_regions2.h, "sweep
+    // rounds": a bin whose turn comes with its count still at the level has lost no cell since the sweep began)
+    int b = -1, bv = 0, nev = 0;
+    bool part = false;
+    unsigned long long partmask = 0ull;
+    if (cont_level > 0) {  // an unfinished sweep goes on without an arg-max: the listed bins still at the level, in lane order
+      part = cont_b >= 0 && hist[cont_b >= 0 ? cont_b : 0] == cont_level;
+      partmask = __ballot(part);
+      if (partmask) {
+        b = part ? cont_b : -1;
+        bv = cont_level;
+        nev = static_cast<int>(__popcll(partmask));
+      }
+    }
+    if (!partmask) {
+      uint32_t key = 0;
+      uint32_t cntq[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (q < nsets) {
+          cntq[q] = mybin[q] >= 0 ? static_cast<uint32_t>(hist[mybin[q]]) : 0u;
+          const uint32_t k = (cntq[q] << 8) | static_cast<uint32_t>(255 - q);
+          key = k > key ? k : key;
+        }
+      for (int q = 4; q < nsets; ++q) {
+        const int t = lane + 64 * q;
+        const uint32_t cnt = t < nnz ? static_cast<uint32_t>(hist[nzlist[t]]) : 0u;
+        const uint32_t k = (cnt << 8) | static_cast<uint32_t>(255 - (q < 255 ? q : 255));
+        key = k > key ? k : key;
+      }
+      key = wave_max_u32(key);
+      bv = static_cast<int>(key >> 8);
+      int qc = 255 - static_cast<int>(key & 255u);
+      if (bv <= 0) break;
+      // seed_candidates.size() < min_region_growing_candidate_size (size_t comparison, plane_extractor.cpp:305)
+      if (static_cast<unsigned long long>(bv) < static_cast<unsigned long long>(static_cast<long long>(prm.min_cand))) break;
+      if (qc >= 255)
+        for (qc = 255; qc < nsets; ++qc) {
+          const int t = lane + 64 * qc;
+          if (__ballot(t < nnz && hist[nzlist[t]] == bv)) break;
+        }
+      if (qc < 4) {
+        b = mybin[0];
+        b = qc == 1 ? mybin[1] : b;
+        b = qc == 2 ? mybin[2] : b;
+        b = qc == 3 ? mybin[3] : b;
+        uint32_t cs_ = cntq[0];
+        cs_ = qc == 1 ? cntq[1] : cs_;
+        cs_ = qc == 2 ? cntq[2] : cs_;
+        cs_ = qc == 3 ? cntq[3] : cs_;
+        part = b >= 0 && cs_ == static_cast<uint32_t>(bv);
+      } else {
+        const int t = lane + 64 * qc;
+        b = t < nnz ? static_cast<int>(nzlist[t]) : -1;
+        part = b >= 0 && hist[b >= 0 ? b : 0] == bv;
+      }
+      partmask = __ballot(part);
+      nev = static_cast<int>(__popcll(partmask));
+      if (qc + 1 < nsets && nev < 64) {  // the bins at the level of the later chunks fire right after these
+        int total = nev;
+        bool staged = false;
+        auto append = [&](int bq, uint32_t cq) {
+          const bool pq = bq >= 0 && cq == static_cast<uint32_t>(bv);
+          const unsigned long long mq = __ballot(pq);
+          if (mq) {
+            if (!staged) {
+              if (part) evb[__popcll(partmask & lt_mask)] = static_cast<uint16_t>(b);
+              staged = true;
+            }
+            const int at = total + static_cast<int>(__popcll(mq & lt_mask));
+            if (pq && at < 64) evb[at] = static_cast<uint16_t>(bq);
+            total += static_cast<int>(__popcll(mq));
+          }
+        };
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+          if (q > qc && q < nsets && total < 64) append(mybin[q], cntq[q]);
+        for (int q = qc + 1 > 4 ? qc + 1 : 4; q < nsets && total < 64; ++q) {
+          const int t = lane + 64 * q;
+          const int bq = t < nnz ? static_cast<int>(nzlist[t]) : -1;
+          append(bq, bq >= 0 ? static_cast<uint32_t>(hist[bq]) : 0u);
+        }
+        if (staged) {
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
+          nev = total < 64 ? total : 64;
+          part = lane < nev;
+          b = part ? static_cast<int>(evb[lane]) : -1;
+          partmask = nev == 64 ? ~0ull : ((1ull << nev) - 1ull);
+        }
+      }
+      cont_b = part ? b : -1;
+      cont_level = bv;
+    }
+    const int bs = b >= 0 ? b : 0;
+    // ---- seeds: the first live entry of each bin's list (sorted by mse, then cell id: plane_extractor.cpp:309-316)
+    int pos = static_cast<int>(bin_start[bs]);
+    const int lend = cursor[bs];
+    unsigned long long e64 = candc[bs];
+    bool need = part && (e64 == kNone || !alive(static_cast<uint32_t>(e64) & kCellMask));
+    bool broken = false;
+    if (__ballot(need)) {
+      if (need) {
+        if (e64 != kNone) ++pos;  // the cached entry died (taken by another bin's grow)
+        if (pos >= lend) {        // cannot happen (a bin's count is the number of live entries of its list): safety net
+          broken = true;
+          need = false;
+        } else {
+          const int i1 = pos + 1 < lend ? pos + 1 : lend - 1, i2 = pos + 2 < lend ? pos + 2 : lend - 1, i3 = pos + 3 < lend ? pos + 3 : lend - 1;
+          const unsigned long long e0 = order[pos], e1 = order[i1], e2 = order[i2], e3 = order[i3];
+          if (alive(static_cast<uint32_t>(e0) & kCellMask)) { e64 = e0; need = false; }
+          else if (pos + 1 < lend && alive(static_cast<uint32_t>(e1) & kCellMask)) { e64 = e1; pos += 1; need = false; }
+          else if (pos + 2 < lend && alive(static_cast<uint32_t>(e2) & kCellMask)) { e64 = e2; pos += 2; need = false; }
+          else if (pos + 3 < lend && alive(static_cast<uint32_t>(e3) & kCellMask)) { e64 = e3; pos += 3; need = false; }
+          else pos += 4;
+        }
+      }
+      unsigned long long nm = __ballot(need);
+      while (nm) {  // the wave together, 64 entries per step: behind a large grow a list's front is dead for a long stretch
+        const int l = static_cast<int>(__builtin_ctzll(nm));
+        nm &= nm - 1ull;
+        int p = __builtin_amdgcn_readlane(pos, l);
+        const int e = __builtin_amdgcn_readlane(lend, l);
+        unsigned long long found = kNone;
+        while (p < e) {
+          const int i = p + lane;
+          unsigned long long ce = 0ull;
+          bool al = false;
+          if (i < e) {
+            ce = order[i];
+            al = alive(static_cast<uint32_t>(ce) & kCellMask);
+          }
+          const unsigned long long am = __ballot(al);
+          if (DBG) ++n_scan64;
+          if (am) {
+            const int first = static_cast<int>(__builtin_ctzll(am));
+            const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(ce)), first));
+            const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(ce >> 32)), first));
+            found = (static_cast<unsigned long long>(hi) << 32) | lo;
+            p += first;
+            break;
+          }
+          p += 64;
+        }
+        if (lane == l) {
+          need = false;
+          pos = p;
+          if (found == kNone) broken = true;
+          else e64 = found;
+        }
+      }
+    }
+    if (__ballot(broken)) break;
+    const uint32_t cell = static_cast<uint32_t>(e64) & kCellMask;
+    const uint32_t cstart_ = static_cast<uint32_t>(e64 >> kE64StartShift) & kCellMask;
+    const int csz = part ? static_cast<int>(static_cast<uint32_t>(e64 >> kE64SizeShift) & kCoreSizeMask) : 0;
+    const bool cout_ = ((e64 >> kE64OutShift) & 1ull) != 0ull;
+    // ---- which events fire.  A grow from a core without a one-way edge out takes exactly that core, so events interact
+    // only through the histogram: a bin that loses a cell to a lower lane THAT FIRES is no longer at the level when its
+    // turn comes and is skipped (that covers a lower lane taking this lane's seed too).  Every cell of a multi-cell core
+    // is an ITEM, one wave lane each: it claims its bin with min(source lane), and on commit leaves the bitmap and the
+    // histogram.  Large cores and cores with a one-way edge out stop the round and fire alone ("wide").
+    bool complete = part && csz <= kItemMax && !cout_;
+    int cnt = (complete && csz > 1) ? csz : 0;
+    const int incl_items = wave_incl_scan_i32(cnt);
+    if (cnt > 0 && incl_items > 64) {  // (any give-up is exact: the event waits for a later round or fires alone)
+      complete = false;
+      cnt = 0;
+    }
+    const unsigned long long multi = __ballot(cnt > 0);
+    uint32_t lowb = 0xFFFFFFFFu;
+    bool it_ok = false;
+    int it_src = 0, it_bin = -1;
+    uint32_t it_cell = 0;
+    if (multi) {
+      if (DBG) ++n_multi;
+      const int off = incl_items - cnt;
+      const int nitems = static_cast<int>(wave_max_u32(cnt > 0 ? static_cast<uint32_t>(incl_items) : 0u));
+      rrec[lane] = make_uint2(cstart_, static_cast<uint32_t>(off));
+#pragma unroll
+      for (int i = 0; i < kItemMax; ++i)
+        if (i < cnt) rsrc[off + i] = static_cast<uint8_t>(lane);
+      asm volatile("" ::: "memory");  // (LDS executes a wave's operations in order; only the compiler must keep it)
+      __builtin_amdgcn_wave_barrier();
+      it_ok = lane < nitems;
+      if (it_ok) {
+        it_src = static_cast<int>(rsrc[lane]);
+        const uint2 r = rrec[it_src];
+        const uint32_t ce = corecells[r.x + static_cast<uint32_t>(lane) - r.y];
+        it_cell = ce & kCellMask;
+        const int bn = static_cast<int>(ce >> kCellBits);
+        it_bin = (bn >= 1 && bn - 1 < nb) ? bn - 1 : -1;
+        if (it_bin >= 0) atomicMin(&bclaim[it_bin], static_cast<uint32_t>(it_src));
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (part) lowb = bclaim[bs];
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (it_ok && it_bin >= 0) bclaim[it_bin] = 0xFFFFFFFFu;  // clean for the next round
+    }
+    const bool flag = part && (!complete || lowb < static_cast<uint32_t>(lane));
+    unsigned long long fl = __ballot(flag), skipped = 0ull;
+    int stop = 64;
+    bool stop_wide = false;
+    while (fl) {  // lanes in order; only the flagged ones need a look
+      const int t = static_cast<int>(__builtin_ctzll(fl));
+      fl &= fl - 1ull;
+      const uint32_t mb = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(lowb), t));
+      if (mb < static_cast<uint32_t>(t)) {
+        if (((skipped >> mb) & 1ull) == 0ull) {  // its bin lost a cell to a lane that fires: not at the level any more
+          skipped |= 1ull << t;
+          if (DBG) ++n_skip;
+          continue;
+        }
+        stop = t;  // the lowest claimant was itself skipped — what the other claimants did is unknown: next round
+        break;
+      }
+      stop = t;  // a large or irregular grow whose bin nobody touched: it fires now, alone
+      stop_wide = true;
+      break;
+    }
+    // ---- commit the lanes that fire before the stop
+    const unsigned long long cm = (stop >= 64 ? partmask : (partmask & ((1ull << stop) - 1ull))) & ~skipped;
+    const bool cmt = ((cm >> lane) & 1ull) != 0ull;
+    if (part) {
+      const bool used = cmt || (stop_wide && lane == stop);
+      bin_start[bs] = static_cast<uint32_t>(used ? pos + 1 : pos);
+      candc[bs] = used ? kNone : e64;
+    }
+    if (cm) {
+      const int grank = static_cast<int>(__popcll(cm & lt_mask));
+      const int ncm = static_cast<int>(__popcll(cm));
+      const int myn = cmt ? csz : 0;
+      int base, total;
+      if (!(multi & cm)) {  // (uniform) one cell each
+        base = tail + grank;
+        total = ncm;
+      } else {
+        const int incl = wave_incl_scan_i32(myn);
+        total = __builtin_amdgcn_readlane(incl, 63);
+        base = tail + incl - myn;
+      }
+      if (cmt && csz == 1) {
+        kill(cell);
+        atomicSub(&hist[bs], 1);  // hist.removePoint
+      }
+      if ((multi & cm) && it_ok && ((cm >> it_src) & 1ull) != 0ull) {
+        kill(it_cell);
+        if (it_bin >= 0) atomicSub(&hist[it_bin], 1);
+      }
+      // cells_to_merge.size() < min_region_growing_cells_activated (size_t comparison, plane_extractor.cpp:329)
+      const bool want_cand = cmt && !(static_cast<unsigned long long>(csz) < static_cast<unsigned long long>(static_cast<long long>(prm.min_cells)));
+      const unsigned long long wantmask = __ballot(want_cand);
+      if (wantmask) {
+        const int crank = static_cast<int>(__popcll(wantmask & lt_mask));
+        if (want_cand && ncand + crank < sb.pcap) {
+          cand_grow[ncand + crank] = make_uint4(static_cast<uint32_t>(ngrow + grank), static_cast<uint32_t>(base), static_cast<uint32_t>(base + csz), cell);
+          cgrow[cstart_] = static_cast<uint32_t>(ngrow + grank + 1);
+        }
+        const int nwant = static_cast<int>(__popcll(wantmask));
+        ncand += nwant < sb.pcap - ncand ? nwant : (sb.pcap - ncand > 0 ? sb.pcap - ncand : 0);
+      }
+      tail = __builtin_amdgcn_readfirstlane(tail + total);
+      ngrow += ncm;
+      remaining -= total;
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (!stop_wide) continue;
+    // ---- the stopping event fires alone: every cell of its core(s) leaves the bitmap and the histogram, 64 per step
+    if (DBG) ++n_wide;
+    const uint32_t wcell = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cell), stop));
+    const uint32_t wstart = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cstart_), stop));
+    const int wsz = __builtin_amdgcn_readlane(csz, stop);
+    const bool wout = ((__ballot(cout_) >> stop) & 1ull) != 0ull;
+    int gsize = 0;
+    auto take_core = [&](uint32_t st, int sz, uint32_t root, bool follow) {
+      for (int i = 0; i < sz; i += 64) {
+        const bool in = i + lane < sz;
+        const uint32_t ce = in ? corecells[st + static_cast<uint32_t>(i + lane)] : 0u;
+        const uint32_t cl = ce & kCellMask;
+        if (in) {
+          kill(cl);
+          const int bn = static_cast<int>(ce >> kCellBits);
+          if (bn >= 1 && bn - 1 < nb) atomicSub(&hist[bn - 1], 1);
+          if (follow) {  // one-way edges out of this cell: their targets' cores join the grow if they are still alive
+            const uint32_t m = sb.meta[fo + cl];
+            const uint32_t ow = ((m >> 2) & ~(m >> 8)) & 0xFu;
+#pragma unroll
+            for (int dir = 0; dir < 4; ++dir)
+              if ((ow >> dir) & 1u) {
+                const int v = static_cast<int>(cl) + (dir == 0 ? -nh : (dir == 1 ? nh : (dir == 2 ? -1 : 1)));
+                const uint32_t rv = sb.parent[fo + v];
+                if (rv != root) {
+                  // a core is alive as long as its root's bit is set; whoever clears it has found the core
+                  const uint32_t bit = 1u << (rv & 31u);
+                  const uint32_t old = atomicAnd(&abits[rv >> 5], ~bit);
+                  if (old & bit) sb.worklist[fo + static_cast<uint32_t>(atomicAdd(&hdr[8], 1))] = rv;
+                }
+              }
+          }
+        }
+      }
+      gsize += sz;
+    };
+    if (!wout) {
+      take_core(wstart, wsz, 0u, false);
+    } else {
+      if (DBG) ++n_irreg;
+      // the cores reachable from the seed's core over one-way edges, in any order (the SET is what the sequence needs)
+      const uint32_t root0 = sb.parent[fo + wcell];
+      if (lane == 0) {
+        hdr[8] = 1;
+        sb.worklist[fo] = root0;
+        kill(root0);
+      }
+      wave_sync();
+      for (int wi = 0;; ++wi) {
+        const int nwl = *static_cast<volatile int*>(&hdr[8]);
+        if (wi >= nwl) break;
+        const uint32_t r = __hip_atomic_load(sb.worklist + fo + wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t st = sb.cstart[fo + r];
+        const int sz = static_cast<int>(sb.csize[fo + r] & kCoreSizeMask);
+        take_core(st, sz, r, true);
+        wave_sync();
+      }
+    }
+    const bool is_cand = !(static_cast<unsigned long long>(gsize) < static_cast<unsigned long long>(static_cast<long long>(prm.min_cells))) && ncand < sb.pcap;
+    if (is_cand) {
+      if (!wout) {
+        if (lane == 0) cgrow[wstart] = static_cast<uint32_t>(ngrow + 1);
+      } else {
+        const int nwl = hdr[8];
+        for (int i = lane; i < nwl; i += 64) cgrow[sb.cstart[fo + sb.worklist[fo + i]]] = static_cast<uint32_t>(ngrow + 1);
+      }
+      if (lane == 0) {
+        cand_grow[ncand] = make_uint4(static_cast<uint32_t>(ngrow), static_cast<uint32_t>(tail), static_cast<uint32_t>(tail + gsize), wcell | kCandWide);
+        biglist[nbig] = static_cast<uint32_t>(ncand);
+      }
+      ++ncand;
+      ++nbig;
+    }
+    tail = __builtin_amdgcn_readfirstlane(tail + gsize);
+    ++ngrow;
+    remaining -= gsize;
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // the header the tail launch starts from (k_regions2 PHASE 3 reads hdr[0..3], its segment counter hdr[40] must be 0)
+  int* ho = sb.hdr_out + static_cast<size_t>(frame) * 48;
+  if (lane < 48) {
+    int v = 0;
+    v = lane == 0 ? planar_total : v;
+    v = lane == 1 ? tail : v;
+    v = lane == 2 ? ngrow : v;
+    v = lane == 3 ? ncand : v;
+    v = lane == kHdrBig ? nbig : v;
+    ho[lane] = v;
+  }
+  if (DBG && sb.dbg && lane == 0) {
+    unsigned long long* d = sb.dbg + static_cast<size_t>(frame) * kDbgSlots;
+    d[1] = static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - t_start;
+    d[11] = n_rounds; d[13] = static_cast<unsigned long long>(ngrow); d[14] = static_cast<unsigned long long>(ncand);
+    d[15] = static_cast<unsigned long long>(tail); d[19] = n_scan64; d[21] = n_wide; d[22] = n_skip; d[23] = n_irreg; d[28] = n_multi;
+  }
+}
+
+// ---- per cell: the grow that took it (candidates only: other grows leave no trace) and its in-edge bits ------------------
+__global__ __launch_bounds__(256) void k_cellgrow(Params prm, CoreBufs cb) {
+  const int frame = blockIdx.y;
+  const int c = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
+  if (c >= prm.C) return;
+  const size_t fo = static_cast<size_t>(frame) * prm.C;
+  const uint32_t m = cb.meta[fo + c];
+  uint32_t q = 0u;
+  if (m & F_UNASSIGNED) {
+    const uint32_t g1 = cb.cgrow[fo + cb.cstart[fo + cb.parent[fo + c]]];
+    q = (g1 << 4) | ((m >> 8) & 0xFu);
+  }
+  cb.cellq[fo + c] = q;
+}
+
+// ---- FIFO activation order of the candidate grows (plane_extractor.cpp:349-392 restricted to the grow's own cells) -------
+// A grow's cells are known (cellq: grow + 1 in the high bits); what is computed here is the order in which growSeed
+// activates them: queue order, then U, D, L, R, a cell going to the first (slot, direction) that reaches it.  Grows are
+// disjoint, so all of them run at once: a task = one "wide" candidate (a whole wave: 16 queue slots x 4 directions per step,
+// duplicates resolved through a small per-wave claim table) or 64 consecutive candidates of up to kItemMax cells (one LANE
+// each: the grow is a list of relative cell codes in a 64-bit register, as in the sweep rounds of dpx_regions2.h).
+struct OrderBufs {
+  uint32_t* cellq;          // [B][C]
+  const uint4* cand_grow;   // [B][pcap]
+  const uint32_t* biglist;  // [B][pcap]
+  const int* hdr;           // [B][48]
+  uint32_t* queue;          // [B][C]
+  int* task;                // [B] task counter (zeroed by k_core_init's launch sequence)
+  unsigned long long* dbg;
+  int pcap;
+};
+constexpr int kOrderWaves = 8;
+constexpr int kOrderClaim = 256;  // claim-table slots per wave
+
+template <bool DBG>
+__global__ __launch_bounds__(kOrderWaves * 64) void k_order(Params prm, OrderBufs ob) {
+  const int frame = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int C = prm.C, nh = prm.nh;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  __shared__ uint32_t s_claim[kOrderWaves][kOrderClaim];
+  uint32_t* ctab = s_claim[wid];
+  for (int i = lane; i < kOrderClaim; i += 64) ctab[i] = 0xFFFFFFFFu;
+  wave_sync();
+  const size_t fo = static_cast<size_t>(frame) * C;
+  uint32_t* cellq = ob.cellq + fo;
+  uint32_t* queue = ob.queue + fo;
+  const uint4* cand_grow = ob.cand_grow + static_cast<size_t>(frame) * ob.pcap;
+  const uint32_t* biglist = ob.biglist + static_cast<size_t>(frame) * ob.pcap;
+  const int* hdr = ob.hdr + static_cast<size_t>(frame) * 48;
+  const int ncand = hdr[3], nbig = hdr[kHdrBig];
+  const int ntasks = nbig + ((ncand + 63) >> 6);
+  const int slot = lane >> 2, dir = lane & 3;
+  const int delta = dir == 0 ? -nh : (dir == 1 ? nh : (dir == 2 ? -1 : 1));
+  const uint32_t opp = static_cast<uint32_t>(dir ^ 1);
+  for (;;) {
+    int t = 0;
+    if (lane == 0) t = atomicAdd(ob.task + frame, 1);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t >= ntasks) break;
+    if (t < nbig) {
+      // ---- one wide grow: wave-wide FIFO BFS over its own cells
+      const uint4 cg = cand_grow[biglist[t]];
+      const uint32_t g1 = cg.x + 1u;
+      const int gs = static_cast<int>(cg.y);
+      const uint32_t seed = cg.w & kCellMask;
+      if (lane == 0) {
+        queue[gs] = seed;
+        cellq[seed] = 0u;  // a cell leaves its grow's membership when it is activated
+      }
+      int head = gs, tail = gs + 1;
+      wave_sync();
+      while (head < tail) {
+        const int nslots = (tail - head) < 16 ? (tail - head) : 16;
+        const bool active = slot < nslots;
+        const int u = static_cast<int>(__hip_atomic_load(queue + head + (active ? slot : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const int vraw = u + delta;
+        const bool inrange = active && vraw >= 0 && vraw < C;
+        const int v = vraw < 0 ? 0 : (vraw >= C ? C - 1 : vraw);
+        const uint32_t w = __hip_atomic_load(cellq + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // v accepts u iff v belongs to this grow, is not activated yet, and its in-edge from u's side is set (an L / R
+        // step across a row end and a step outside the grid have no such edge)
+        bool cnd = inrange && (w >> 4) == g1 && ((w >> opp) & 1u) != 0u;
+        // the lowest lane that reaches a cell wins it: min(lane) per cell in the claim table, linear probing
+        bool win = false;
+        uint32_t h = (static_cast<uint32_t>(v) * 2654435761u) >> 24;  // 8 bits
+        const uint32_t mykey = (static_cast<uint32_t>(v) << 6) | static_cast<uint32_t>(lane);
+        const uint32_t h0 = h;
+        int ntouch = 0;
+        bool pending = cnd;
+        while (__ballot(pending)) {
+          if (pending) atomicMin(&ctab[h], mykey);
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
+          if (pending) {
+            const uint32_t k = ctab[h];
+            ++ntouch;
+            if ((k >> 6) == static_cast<uint32_t>(v)) {  // this slot is v's: its lowest lane wins
+              win = (k & 63u) == static_cast<uint32_t>(lane);
+              pending = false;
+            } else {
+              h = (h + 1u) & (kOrderClaim - 1u);  // another cell's: next slot
+            }
+          }
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
+        }
+        const unsigned long long mask = __ballot(win);
+        if (win) {
+          const int pos = tail + static_cast<int>(__popcll(mask & lt_mask));
+          queue[pos] = static_cast<uint32_t>(v);
+          cellq[v] = 0u;
+        }
+        // leave the table clean: every slot this lane probed (all lanes are done with the table by now)
+        for (int i = 0; i < ntouch; ++i) ctab[(h0 + static_cast<uint32_t>(i)) & (kOrderClaim - 1u)] = 0xFFFFFFFFu;
+        tail = __builtin_amdgcn_readfirstlane(tail + static_cast<int>(__popcll(mask)));
+        head = __builtin_amdgcn_readfirstlane(head + nslots);
+        wave_sync();  // queue / cellq in global memory: the next step's loads must see these stores
+      }
+    } else {
+      // ---- 64 candidates, one lane each: grows of up to kItemMax cells as lists of relative cell codes
+      const int ci = (t - nbig) * 64 + lane;
+      uint4 cg = make_uint4(0u, 0u, 0u, kCandWide);
+      if (ci < ncand) cg = cand_grow[ci];
+      bool act = (cg.w & kCandWide) == 0u;
+      const bool mine = act;
+      const uint32_t g1 = cg.x + 1u;
+      const int cs = static_cast<int>(cg.w & kCellMask);
+      unsigned long long ll = 0x88ull;  // entry 0 = the seed, code (8, 8)
+      int n = 1, hpop = 0;
+      while (__ballot(act)) {
+        const uint32_t code = act ? (static_cast<uint32_t>(ll >> (8 * hpop)) & 0xFFu) : 0x88u;
+        const int cr = static_cast<int>(code >> 4), cc = static_cast<int>(code & 15u);
+        const int u = cs + (cr - 8) * nh + (cc - 8);
+        auto nbq = [&](int v) { return (act && v >= 0 && v < C) ? cellq[v] : 0u; };
+        const uint32_t qU = nbq(u - nh), qD = nbq(u + nh), qL = nbq(u - 1), qR = nbq(u + 1);
+        // v accepts u iff it belongs to this grow and its in-edge from u's side is set (u is v's D / U / R / L neighbour)
+        const bool okU = (qU >> 4) == g1 && ((qU >> 1) & 1u) != 0u;
+        const bool okD = (qD >> 4) == g1 && ((qD >> 0) & 1u) != 0u;
+        const bool okL = (qL >> 4) == g1 && ((qL >> 3) & 1u) != 0u;
+        const bool okR = (qR >> 4) == g1 && ((qR >> 2) & 1u) != 0u;
+        auto visit = [&](bool ok, uint32_t vcode) {
+          const uint32_t rep = __builtin_amdgcn_perm(0u, vcode, 0u);  // the low byte in all four bytes
+          const uint32_t x0 = static_cast<uint32_t>(ll) ^ rep, x1 = static_cast<uint32_t>(ll >> 32) ^ rep;
+          const bool dup = ((((x0 - 0x01010101u) & ~x0) | ((x1 - 0x01010101u) & ~x1)) & 0x80808080u) != 0u;
+          if (ok && act && !dup && n < 8) {
+            ll |= static_cast<unsigned long long>(vcode & 0xFFu) << (8 * n);
+            ++n;
+          }
+        };
+        visit(okU, code - 16u);
+        visit(okD, code + 16u);
+        visit(okL, code - 1u);
+        visit(okR, code + 1u);
+        ++hpop;
+        if (hpop >= n) act = false;
+      }
+      if (mine) {
+        const int gs = static_cast<int>(cg.y), ge = static_cast<int>(cg.z);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (i < n && gs + i < ge) {
+            const uint32_t code = static_cast<uint32_t>(ll >> (8 * i)) & 0xFFu;
+            queue[gs + i] = static_cast<uint32_t>(cs + (static_cast<int>(code >> 4) - 8) * nh + (static_cast<int>(code & 15u) - 8));
+          }
+      }
+    }
+  }
+}
+
+}  // namespace dpx

@@ -206,6 +206,14 @@ class PlaneExtractor:
         _capi.check(_capi.lib().dpx_get_planes(self._h, frame, out.ctypes.data, n, C.byref(got)))
         return out[:n]
 
+    def options(self) -> dict:
+        """Which kernels this handle runs (dpx_get_options): {"regions": "tier2" | "cores" | ..., ...}."""
+        buf = C.create_string_buffer(512)
+        n = _capi.lib().dpx_get_options(self._h, buf, 512)
+        if n < 0:
+            _capi.check(n)
+        return dict(kv.split("=", 1) for kv in buf.value.decode().split(";") if "=" in kv)
+
     def frame_stats(self, frame: int = 0):
         out = np.zeros(1, dtype=_capi.STATS_DTYPE)
         _capi.check(_capi.lib().dpx_get_frame_stats(self._h, frame, out.ctypes.data))

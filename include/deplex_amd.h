@@ -262,7 +262,18 @@ int64_t dpx_planefit_bytes(dpx_handle h, int32_t input_kind, int32_t batch);
  * chunks of the bin list, [29] = grows given up beyond a round's 64th item, [30] = rounds that continued a sweep without an
  * arg-max, [31] = cycles of the CSR merge walk).  enable != 0 switches the diagnostic
  * instantiation on for later calls; never used when timing. */
-int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_t* out24);
+#define DPX_DEBUG_PHASE_WORDS 32
+int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_t* out32 /* DPX_DEBUG_PHASE_WORDS */);
+/* The same switch also times the launches of the core-based region path (dpx_regions3.h; frames beyond ~8 k cells):
+ * out32[1] = cycles of the sequence launch (k_regsim), [2] = cycles of the slowest wave of the order launch, [11] = rounds,
+ * [13..15] = grows, candidates, activations, [19] = 64-entry list-scan steps, [21] = events that fired alone ("wide"),
+ * [22] = events skipped because their bin lost a cell, [23] = wide events with a one-way edge out of their core,
+ * [28] = rounds with multi-cell cores. */
+int dpx_debug_cores_phases(dpx_handle h, int32_t frame, uint64_t* out32 /* DPX_DEBUG_PHASE_WORDS */);
+/* Which kernels a handle runs, as "key=value;..." (regions = tier2 | tier1 | tier0 | tier0-split | cores | v1, plus the
+ * variant switches read at dpx_create): ties a result or a timing to its variant.  Returns the length written (without
+ * the terminating 0), or a negative error. */
+int dpx_get_options(dpx_handle h, char* buf, int32_t cap);
 /* Diagnostic (handles created with DPX_RESIDENCY=1 in the environment): average shader-clock lifetime of a frame's
  * workgroup in the three region launches (preparation, grow, tail) over the frames of the last call — how long each
  * holds its LDS while other kernels share the chip. */

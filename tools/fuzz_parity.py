@@ -94,7 +94,7 @@ for it in range(cases):
         ov["min_region_planarity_score"] = float(rng.choice([0.3, 0.8]))
     if rng.random() < 0.15:
         ov["ransac_refinement"] = 1
-    env = str(rng.choice(["", "", "DPX_REGIONS_LEAN", "DPX_REGIONS_GSTATE", "DPX_REGIONS_NOSPLIT", "DPX_FUSED_LABELS", "DPX_REGIONS_V1", "DPX_PREP_GROW_SPLIT", "DPX_REGIONS_GSPLIT"]))
+    env = str(rng.choice(["", "", "DPX_REGIONS_LEAN", "DPX_REGIONS_GSTATE", "DPX_REGIONS_NOSPLIT", "DPX_FUSED_LABELS", "DPX_REGIONS_V1", "DPX_PREP_GROW_SPLIT", "DPX_REGIONS_GSPLIT", "DPX_REGIONS_CORES", "DPX_REGIONS_CORES", "DPX_REGIONS_CORES"]))
     xyz = bool(rng.random() < 0.3)
     B = int(rng.integers(1, 4))
     seed = int(rng.integers(0, 10000))
