@@ -96,13 +96,15 @@ struct dpx_handle_s {
   uint32_t* d_gqueue = nullptr;
   // region growing through cores (dpx_regions3.h): large frames
   bool cores = false;
-  int core_wb = 0;                            // bitmap words per frame
+  int core_T = 0, core_logT = 0;              // slots of the pair hash table per frame
   size_t lds3_sim = 0;                        // LDS of the one-wave sequence launch
-  uint32_t* d_core = nullptr;                 // one allocation: parent | csize | cstart | cfill | corecells | cgrow | cellq | worklist | biglist
-  uint32_t *d_parent = nullptr, *d_csize = nullptr, *d_cstart = nullptr, *d_cfill = nullptr, *d_corecells = nullptr, *d_cgrow = nullptr,
-           *d_cellq = nullptr, *d_worklist = nullptr, *d_biglist = nullptr, *d_abits = nullptr, *d_ccursor = nullptr;
+  uint32_t* d_core = nullptr;                 // one allocation for the uint32 arrays below
+  uint32_t *d_parent = nullptr, *d_csize = nullptr, *d_npairs = nullptr, *d_pstart = nullptr, *d_pfill = nullptr, *d_noe = nullptr,
+           *d_oestart = nullptr, *d_oefill = nullptr, *d_hkey = nullptr, *d_hcnt = nullptr, *d_corepairs = nullptr, *d_oedges = nullptr,
+           *d_histg = nullptr, *d_cgrow = nullptr, *d_cellq = nullptr, *d_worklist = nullptr, *d_biglist = nullptr, *d_ccursor = nullptr;
   int* d_order_task = nullptr;
-  unsigned long long* d_order64 = nullptr;    // [B][C] seed lists with each cell's core beside it
+  unsigned long long* d_hbest = nullptr;      // [B][T]
+  uint4* d_lists = nullptr;                   // [B][C] seed lists, one entry per (core, bin) pair
   // staging for the host-pointer API (lazy)
   void* d_in = nullptr;
   size_t d_in_bytes = 0;
@@ -157,7 +159,8 @@ void free_all(dpx_handle h) {
   hipFree(h->d_gowner);
   hipFree(h->d_gqueue);
   hipFree(h->d_core);
-  hipFree(h->d_order64);
+  hipFree(h->d_hbest);
+  hipFree(h->d_lists);
   hipFree(h->d_sort_keys);
   hipFree(h->d_bin_off);
   hipFree(h->d_gqpos);
@@ -358,10 +361,11 @@ struct SubBatch {
 
 dpx::CoreBufs core_bufs(dpx_handle h) {
   dpx::CoreBufs cb{};
-  cb.meta = h->d_meta; cb.parent = h->d_parent; cb.csize = h->d_csize; cb.cstart = h->d_cstart; cb.cfill = h->d_cfill;
-  cb.corecells = h->d_corecells; cb.cgrow = h->d_cgrow; cb.abits = h->d_abits; cb.cursor = h->d_ccursor; cb.cellq = h->d_cellq;
-  cb.order_task = h->d_order_task;
-  cb.Wb = h->core_wb;
+  cb.meta = h->d_meta; cb.mse_c = h->d_mse_c; cb.parent = h->d_parent; cb.csize = h->d_csize; cb.npairs = h->d_npairs; cb.pstart = h->d_pstart;
+  cb.pfill = h->d_pfill; cb.noe = h->d_noe; cb.oestart = h->d_oestart; cb.oefill = h->d_oefill; cb.hkey = h->d_hkey; cb.hcnt = h->d_hcnt;
+  cb.hbest = h->d_hbest; cb.corepairs = h->d_corepairs; cb.oedges = h->d_oedges; cb.keys = h->d_sort_keys; cb.histg = h->d_histg;
+  cb.cgrow = h->d_cgrow; cb.cursor = h->d_ccursor; cb.cellq = h->d_cellq; cb.order_task = h->d_order_task;
+  cb.T = h->core_T; cb.logT = h->core_logT; cb.Cpad = h->Cpad;
   return cb;
 }
 
@@ -370,7 +374,8 @@ void launch_binsort(dpx_handle h, const dpx::Params& prm, hipStream_t s) {
   const int Cpad = h->Cpad, B = prm.batch;
   const long long slots = static_cast<long long>(B) * Cpad;
   const unsigned g256 = static_cast<unsigned>((slots + 255) / 256);
-  hipLaunchKernelGGL(dpx::k_sort_build, dim3(g256), dim3(256), 0, s, prm, h->d_meta, h->d_mse_c, h->d_sort_keys, Cpad);
+  if (!h->cores)  // (the core path's keys, one per (core, bin) pair, come from k_pair_scatter)
+    hipLaunchKernelGGL(dpx::k_sort_build, dim3(g256), dim3(256), 0, s, prm, h->d_meta, h->d_mse_c, h->d_sort_keys, Cpad);
   const int tile = Cpad < dpx::kSortTile ? Cpad : dpx::kSortTile;
   const unsigned tiles = static_cast<unsigned>(slots / tile);
   const size_t lds = static_cast<size_t>(tile) * 8;
@@ -381,7 +386,7 @@ void launch_binsort(dpx_handle h, const dpx::Params& prm, hipStream_t s) {
     hipLaunchKernelGGL(dpx::k_sort_tile, dim3(tiles), dim3(dpx::kSortThreads), lds, s, h->d_sort_keys, Cpad, tile, k);
   }
   if (h->cores) {
-    hipLaunchKernelGGL(dpx::k_sort_lists64, dim3(g256), dim3(256), 0, s, prm, h->d_sort_keys, Cpad, core_bufs(h), h->d_order64, h->d_bin_off);
+    hipLaunchKernelGGL(dpx::k_sort_lists_pairs, dim3(g256), dim3(256), 0, s, prm, h->d_sort_keys, Cpad, core_bufs(h), h->d_lists, h->d_bin_off);
   } else {
     hipLaunchKernelGGL(dpx::k_sort_lists, dim3(g256), dim3(256), 0, s, prm, h->d_sort_keys, Cpad, h->d_order, h->d_bin_off);
   }
@@ -483,13 +488,19 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   if (total > 0 && h->regions_tier != 2)
     hipLaunchKernelGGL(dpx::k_cellgraph, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, prm, h->d_cells, h->d_meta, h->d_mse_c);
   const dim3 cell_grid(static_cast<unsigned>((prm.C + 255) / 256), static_cast<unsigned>(batch));
-  if (total > 0 && h->cores && !skip_r) {  // cores of the symmetric edges (dpx_regions3.h), before the seed lists that carry them
+  if (total > 0 && h->cores && !skip_r) {  // cores of the symmetric edges and their (core, bin) pairs (dpx_regions3.h), before the seed lists
     const dpx::CoreBufs cb = core_bufs(h);
-    hipLaunchKernelGGL(dpx::k_core_init, cell_grid, dim3(256), 0, s, prm, cb);
+    const int nbins = prm.hist_B * prm.hist_B;
+    const int n_init = std::max(std::max(prm.C, h->core_T), std::max(h->Cpad, nbins));
+    const dim3 g_init(static_cast<unsigned>((n_init + 255) / 256), static_cast<unsigned>(batch));
+    const dim3 g_tab(static_cast<unsigned>((h->core_T + 255) / 256), static_cast<unsigned>(batch));
+    const dim3 g_sc(static_cast<unsigned>((std::max(prm.C, h->core_T) + 255) / 256), static_cast<unsigned>(batch));
+    hipLaunchKernelGGL(dpx::k_core_init, g_init, dim3(256), 0, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_core_link, cell_grid, dim3(256), 0, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_core_flatten, cell_grid, dim3(256), 0, s, prm, cb);
+    hipLaunchKernelGGL(dpx::k_pair_count, g_tab, dim3(256), 0, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_core_alloc, cell_grid, dim3(256), 0, s, prm, cb);
-    hipLaunchKernelGGL(dpx::k_core_scatter, cell_grid, dim3(256), 0, s, prm, cb);
+    hipLaunchKernelGGL(dpx::k_pair_scatter, g_sc, dim3(256), 0, s, prm, cb);
   }
   if (total > 0 && (h->regions_tier == 1 || h->regions_tier == 0) && !skip_r) launch_binsort(h, prm, s);
   if (prof) DPX_HIP(hipEventRecord(ev[3], s));
@@ -514,20 +525,26 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   } else if (h->cores) {
     if (total > 0) {
       dpx::SimBufs sb{};
-      sb.order64 = h->d_order64; sb.bin_off = h->d_bin_off; sb.abits0 = h->d_abits; sb.corecells = h->d_corecells; sb.meta = h->d_meta;
-      sb.parent = h->d_parent; sb.csize = h->d_csize; sb.cstart = h->d_cstart; sb.cgrow = h->d_cgrow; sb.worklist = h->d_worklist;
+      sb.lists = h->d_lists; sb.bin_off = h->d_bin_off; sb.histg = h->d_histg; sb.corepairs = h->d_corepairs; sb.oedges = h->d_oedges;
+      sb.parent = h->d_parent; sb.csize = h->d_csize; sb.npairs = h->d_npairs; sb.pstart = h->d_pstart; sb.noe = h->d_noe; sb.oestart = h->d_oestart;
+      sb.cursor = h->d_ccursor; sb.cgrow = h->d_cgrow; sb.worklist = h->d_worklist;
       sb.cand_grow = reinterpret_cast<uint4*>(h->d_cand_grow); sb.biglist = h->d_biglist;
-      sb.hdr_out = reinterpret_cast<int*>(h->d_lds_img); sb.pcap = h->pcap; sb.Wb = h->core_wb;
+      sb.hdr_out = reinterpret_cast<int*>(h->d_lds_img); sb.pcap = h->pcap;
       sb.dbg = h->d_dbg ? h->d_dbg + static_cast<size_t>(h->max_batch) * dpx::kDbgSlots : nullptr;
       dpx::OrderBufs ob{};
       ob.cellq = h->d_cellq; ob.cand_grow = reinterpret_cast<const uint4*>(h->d_cand_grow); ob.biglist = h->d_biglist;
       ob.hdr = reinterpret_cast<const int*>(h->d_lds_img); ob.queue = h->d_gqueue; ob.task = h->d_order_task; ob.pcap = h->pcap;
       ob.dbg = sb.dbg;
       const int per_frame = std::max(1, std::min(16, 512 / std::max(1, batch)));
+      if (h->d_dbg) (void)hipMemsetAsync(h->d_dbg + (static_cast<size_t>(h->max_batch)) * dpx::kDbgSlots, 0, static_cast<size_t>(batch) * dpx::kDbgSlots * 8, s);
       if (h->d_dbg) hipLaunchKernelGGL(dpx::k_regsim<true>, dim3(batch), dim3(64), h->lds3_sim, s, prm, sb);
       else hipLaunchKernelGGL(dpx::k_regsim<false>, dim3(batch), dim3(64), h->lds3_sim, s, prm, sb);
       hipLaunchKernelGGL(dpx::k_cellgrow, cell_grid, dim3(256), 0, s, prm, core_bufs(h));
-      hipLaunchKernelGGL(dpx::k_order<false>, dim3(per_frame, batch), dim3(dpx::kOrderWaves * 64), 0, s, prm, ob);
+      if (h->d_dbg) {
+        hipLaunchKernelGGL(dpx::k_order<true>, dim3(per_frame, batch), dim3(dpx::kOrderWaves * 64), 0, s, prm, ob);
+      } else {
+        hipLaunchKernelGGL(dpx::k_order<false>, dim3(per_frame, batch), dim3(dpx::kOrderWaves * 64), 0, s, prm, ob);
+      }
       if (h->d_dbg) hipLaunchKernelGGL((dpx::k_regions2<0, true, 3>), dim3(batch), dim3(dpx::kTailRT), h->lds2_p3, s, prm, rb, rx);
       else hipLaunchKernelGGL((dpx::k_regions2<0, false, 3>), dim3(batch), dim3(dpx::kTailRT), h->lds2_p3, s, prm, rb, rx);
     }
@@ -990,13 +1007,14 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
       const bool named_old = (v1 && v1[0] == '1') || want_lean || want_gst || (gsplit && gsplit[0] == '1') || (v2 && v2[0] == '1') || (force && force[0] == '1');
       const int Ci = static_cast<int>(C), nbi = static_cast<int>(nb);
       const dpx::R2Layout l0 = dpx::r2_layout(0, Ci, nbi, nh);
-      const int wb = 2 * ((Ci + 63) / 64);
       const bool fits_cores = nb < 4600 && C >= 1 && C < (size_t(1) << dpx::kKeyCellBits) && l0.tail_end <= kLdsLimit &&
-                              dpx::s3_layout(nbi, wb).end <= kLdsLimit;
+                              dpx::s3_layout(nbi, Ci).end <= kLdsLimit;
       if (fits_cores && (force_cores || (!named_old && h->regions_tier != 2))) {
         h->cores = true;
-        h->core_wb = wb;
-        h->lds3_sim = dpx::s3_layout(nbi, wb).end;
+        h->core_logT = 6;
+        while ((size_t(1) << h->core_logT) < 2 * C) ++h->core_logT;
+        h->core_T = 1 << h->core_logT;
+        h->lds3_sim = dpx::s3_layout(nbi, Ci).end;
         h->regions_tier = 0;
         h->tier0_split = false;
         h->sort_pad = 0;
@@ -1040,22 +1058,17 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
     A(dev_alloc(&h->d_gqueue, B * C));
   }
   if (h->cores) {
-    const size_t wbs = static_cast<size_t>(h->core_wb);
-    A(dev_alloc(&h->d_core, B * (9 * C + wbs + 2)));
-    A(dev_alloc(&h->d_order64, B * C));
+    const size_t T = static_cast<size_t>(h->core_T);
+    A(dev_alloc(&h->d_core, B * (17 * C + 2 * T + static_cast<size_t>(nb) + 8)));
+    A(dev_alloc(&h->d_hbest, B * T));
+    A(dev_alloc(&h->d_lists, B * C));
     if (rc == DPX_OK) {
       uint32_t* q = h->d_core;
-      h->d_parent = q; q += B * C;
-      h->d_csize = q; q += B * C;
-      h->d_cstart = q; q += B * C;
-      h->d_cfill = q; q += B * C;
-      h->d_corecells = q; q += B * C;
-      h->d_cgrow = q; q += B * C;
-      h->d_cellq = q; q += B * C;
-      h->d_worklist = q; q += B * C;
-      h->d_biglist = q; q += B * C;
-      h->d_abits = q; q += B * wbs;
-      h->d_ccursor = q; q += B;
+      auto take = [&](uint32_t*& dst, size_t n) { dst = q; q += B * n; };
+      take(h->d_parent, C); take(h->d_csize, C); take(h->d_npairs, C); take(h->d_pstart, C); take(h->d_pfill, C); take(h->d_noe, C);
+      take(h->d_oestart, C); take(h->d_oefill, C); take(h->d_corepairs, C); take(h->d_cgrow, C); take(h->d_cellq, C); take(h->d_worklist, C);
+      take(h->d_biglist, C); take(h->d_oedges, 4 * C); take(h->d_hkey, T); take(h->d_hcnt, T); take(h->d_histg, static_cast<size_t>(nb));
+      take(h->d_ccursor, 4);
       h->d_order_task = reinterpret_cast<int*>(q);
     }
   }

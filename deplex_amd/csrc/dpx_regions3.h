@@ -30,23 +30,40 @@ constexpr uint32_t kCoreOut = 0x80000000u;     // csize[root]: a one-way edge le
 constexpr uint32_t kCoreSizeMask = 0x000FFFFFu;
 constexpr int kCellBits = kKeyCellBits;        // 19: C < 2^19
 constexpr uint32_t kCellMask = (1u << kCellBits) - 1u;
-// seed-list entry (order64): cell | core start << 19 | core size << 38 | one-way-out << 58
-constexpr int kE64StartShift = kCellBits, kE64SizeShift = 2 * kCellBits, kE64OutShift = 2 * kCellBits + 20;
-constexpr int kItemMax = 8;  // cores of up to this many cells are handled inside a sweep round (one item per cell)
+constexpr int kPairBinBits = 13;               // bins < 2^13 (dpx_binsort.h)
+constexpr uint32_t kPairBinMask = (1u << kPairBinBits) - 1u;
+constexpr uint32_t kPairEmpty = 0xFFFFFFFFu;
+constexpr int kItemMax = 8;  // cores of up to this many PAIRS are handled inside a sweep round (one item per pair)
 
+// What the sequence of grows needs to know about a frame is proportional to its (core, bin) PAIRS, not its cells:
+//   * the seed of a bin is its minimum-(MSE, cell id) live cell (plane_extractor.cpp:309-316), and a core's cells die
+//     together — so of the cells a core has in a bin only the best one (the pair's LEADER) can ever be a seed, and the
+//     seed lists hold one entry per pair;
+//   * a grow takes cores whole, so what it does to the histogram is the (bin, count) list of its cores' pairs, and whether
+//     a cell is still unassigned is one bit per core.
 struct CoreBufs {
-  const uint32_t* meta;  // [B][C]   k_cellgraph
-  uint32_t* parent;      // [B][C]   union-find forest; after k_core_flatten: the core's root (its lowest cell id)
-  uint32_t* csize;       // [B][C]   at the root: cells of the core | kCoreOut
-  uint32_t* cstart;      // [B][C]   at the root: first slot of the core in corecells
-  uint32_t* cfill;       // [B][C]   at the root: scatter cursor
-  uint32_t* corecells;   // [B][C]   cells grouped by core: cell | (bin + 1) << 19
-  uint32_t* cgrow;       // [B][C]   indexed by core start: grow index + 1 (k_regsim)
-  uint32_t* abits;       // [B][Wb]  planar bitmap (bit c of the frame)
-  uint32_t* cursor;      // [B]      allocation cursor of corecells
-  uint32_t* cellq;       // [B][C]   k_cellgrow: (grow + 1) << 4 | in-edge bits
-  int* order_task;       // [B]      task counter of k_order
-  int Wb;                // bitmap words per frame (even)
+  const uint32_t* meta;   // [B][C]   k_cellgraph
+  const float* mse_c;     // [B][C]
+  uint32_t* parent;       // [B][C]   union-find forest; after k_core_flatten: the core's root (its lowest cell id)
+  uint32_t* csize;        // [B][C]   at the root: cells of the core
+  uint32_t* npairs;       // [B][C]   at the root: (core, bin) pairs
+  uint32_t* pstart;       // [B][C]   at the root: first slot of the core in corepairs = the core's ID
+  uint32_t* pfill;        // [B][C]
+  uint32_t* noe;          // [B][C]   at the root: one-way edges to other cores (duplicates included)
+  uint32_t* oestart;      // [B][C]
+  uint32_t* oefill;       // [B][C]
+  uint32_t* hkey;         // [B][T]   hash table of the pairs: root << 13 | bin
+  uint32_t* hcnt;         // [B][T]   cells of the pair
+  unsigned long long* hbest;  // [B][T] min(mse key << 19 | cell): the pair's leader
+  uint32_t* corepairs;    // [B][C]   pairs grouped by core: bin | count << 13
+  uint32_t* oedges;       // [B][4C]  one-way edges grouped by source core: root of the target's core
+  unsigned long long* keys;  // [B][Cpad] sort keys of the seed lists (dpx_binsort.h), one per pair
+  uint32_t* histg;        // [B][nb]  cells per histogram bin
+  uint32_t* cgrow;        // [B][C]   indexed by core ID: grow index + 1 (k_regsim)
+  uint32_t* cursor;       // [B][4]   allocation cursors of corepairs / oedges, planar cells of the frame
+  uint32_t* cellq;        // [B][C]   k_cellgrow: (grow + 1) << 4 | in-edge bits
+  int* order_task;        // [B]      task counter of k_order
+  int T, logT, Cpad;
 };
 
 __device__ __forceinline__ uint32_t cc_load(const uint32_t* p) {
@@ -82,29 +99,48 @@ __device__ __forceinline__ void cc_union(uint32_t* p, uint32_t a, uint32_t b) {
     a = old;  // a was no longer a root: its tree (now under min(old, b)) still has to meet b's
   }
 }
+// slot of pair key K in the frame's table: found or inserted
+__device__ __forceinline__ uint32_t pair_slot(uint32_t* hkey, int logT, uint32_t K) {
+  const uint32_t mask = (1u << logT) - 1u;
+  uint32_t h = (K * 2654435761u) >> (32 - logT);
+  for (;;) {
+    const uint32_t k = cc_load(hkey + h);
+    if (k == K) return h;
+    if (k == kPairEmpty) {
+      const uint32_t old = atomicCAS(hkey + h, kPairEmpty, K);
+      if (old == kPairEmpty || old == K) return h;
+    }
+    h = (h + 1u) & mask;
+  }
+}
 
-// grid (ceil(C / 256), B), 256 threads: thread = cell
+// grid (ceil(max(C, T, Cpad) / 256), B), 256 threads
 __global__ __launch_bounds__(256) void k_core_init(Params prm, CoreBufs cb) {
   const int frame = blockIdx.y;
-  const int c = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
+  const int i = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
   const size_t fo = static_cast<size_t>(frame) * prm.C;
-  bool planar = false;
-  if (c < prm.C) {
-    planar = (cb.meta[fo + c] & F_UNASSIGNED) != 0u;
-    cb.parent[fo + c] = static_cast<uint32_t>(c);
-    cb.csize[fo + c] = 0u;
-    cb.cfill[fo + c] = 0u;
-    cb.cgrow[fo + c] = 0u;
+  if (i < prm.C) {
+    cb.parent[fo + i] = static_cast<uint32_t>(i);
+    cb.csize[fo + i] = 0u;
+    cb.npairs[fo + i] = 0u;
+    cb.pfill[fo + i] = 0u;
+    cb.noe[fo + i] = 0u;
+    cb.oefill[fo + i] = 0u;
+    cb.cgrow[fo + i] = 0u;
   }
-  const unsigned long long m = __ballot(planar);
-  const int w = c >> 5;  // (a wave covers 64 consecutive cells of one frame: two bitmap words)
-  if ((threadIdx.x & 63) == 0 && w < cb.Wb) {
-    uint32_t* ab = cb.abits + static_cast<size_t>(frame) * cb.Wb;
-    ab[w] = static_cast<uint32_t>(m);
-    if (w + 1 < cb.Wb) ab[w + 1] = static_cast<uint32_t>(m >> 32);
+  if (i < cb.T) {
+    const size_t to = static_cast<size_t>(frame) * cb.T + i;
+    cb.hkey[to] = kPairEmpty;
+    cb.hcnt[to] = 0u;
+    cb.hbest[to] = ~0ull;
   }
-  if (c == 0) {
-    cb.cursor[frame] = 0u;
+  if (i < cb.Cpad) cb.keys[static_cast<size_t>(frame) * cb.Cpad + i] = ~0ull;
+  const int nb = prm.hist_B * prm.hist_B;
+  if (i < nb) cb.histg[static_cast<size_t>(frame) * nb + i] = 0u;
+  if (i == 0) {
+    cb.cursor[4 * frame] = 0u;
+    cb.cursor[4 * frame + 1] = 0u;
+    cb.cursor[4 * frame + 2] = 0u;
     cb.order_task[frame] = 0;
   }
 }
@@ -123,58 +159,129 @@ __global__ __launch_bounds__(256) void k_core_link(Params prm, CoreBufs cb) {
   if (sym & 2u) cc_union(p, static_cast<uint32_t>(c), static_cast<uint32_t>(c + prm.nh));
 }
 
-// root of every cell, core sizes, "a one-way edge leaves this core"
+// root of every cell; per core: cells, one-way edges out; per (core, bin) pair: cells and leader
 __global__ __launch_bounds__(256) void k_core_flatten(Params prm, CoreBufs cb) {
   const int frame = blockIdx.y;
   const int c = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
-  if (c >= prm.C) return;
   const size_t fo = static_cast<size_t>(frame) * prm.C;
-  const uint32_t m = cb.meta[fo + c];
-  if (!(m & F_UNASSIGNED)) return;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const uint32_t m = c < prm.C ? cb.meta[fo + c] : 0u;
+  const bool planar = (m & F_UNASSIGNED) != 0u;
   uint32_t* p = cb.parent + fo;
-  const uint32_t r = cc_find(p, static_cast<uint32_t>(c));
-  atomicAdd(cb.csize + fo + r, 1u);
-  const uint32_t ow = ((m >> 2) & ~(m >> 8)) & 0xFu;  // one-way out-edges
-  if (ow) {
-    bool leaves = false;
+  uint32_t r = 0u, K = kPairEmpty;
+  int nout = 0;
+  if (planar) {
+    r = cc_find(p, static_cast<uint32_t>(c));
+    p[c] = r;
+    const int bn = static_cast<int>(m >> META_BIN_SHIFT);
+    if (bn >= 1 && bn - 1 < prm.hist_B * prm.hist_B) K = (r << kPairBinBits) | static_cast<uint32_t>(bn - 1);
+    const uint32_t ow = ((m >> 2) & ~(m >> 8)) & 0xFu;  // one-way out-edges
+    if (ow) {
 #pragma unroll
-    for (int dir = 0; dir < 4; ++dir)
-      if ((ow >> dir) & 1u) {
-        const int v = c + (dir == 0 ? -prm.nh : (dir == 1 ? prm.nh : (dir == 2 ? -1 : 1)));
-        if (cc_find(p, static_cast<uint32_t>(v)) != r) leaves = true;
-      }
-    if (leaves) atomicOr(cb.csize + fo + r, kCoreOut);
+      for (int dir = 0; dir < 4; ++dir)
+        if ((ow >> dir) & 1u) {
+          const int v = c + (dir == 0 ? -prm.nh : (dir == 1 ? prm.nh : (dir == 2 ? -1 : 1)));
+          if (cc_find(p, static_cast<uint32_t>(v)) != r) ++nout;
+        }
+    }
   }
+  if (nout) atomicAdd(cb.noe + fo + r, static_cast<uint32_t>(nout));
+  // neighbouring cells mostly share their core and bin: one atomic per distinct (core) / (core, bin) of the wave — a plane
+  // of 70 000 cells would otherwise put 70 000 atomics on one address
+  unsigned long long todo = __ballot(planar);
+  if (lane == 0 && todo) atomicAdd(cb.cursor + 4 * frame + 2, static_cast<uint32_t>(__popcll(todo)));
+  while (todo) {
+    const int l = static_cast<int>(__builtin_ctzll(todo));
+    const uint32_t r0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(r), l));
+    const unsigned long long same = __ballot(planar && r == r0) & todo;
+    if (lane == l) atomicAdd(cb.csize + fo + r0, static_cast<uint32_t>(__popcll(same)));
+    todo &= ~same;
+  }
+  uint32_t* hkey = cb.hkey + static_cast<size_t>(frame) * cb.T;
+  const unsigned long long val = K != kPairEmpty
+                                     ? (static_cast<unsigned long long>(sort_mse_key(cb.mse_c[fo + c])) << kCellBits) | static_cast<unsigned long long>(c)
+                                     : ~0ull;
+  todo = __ballot(K != kPairEmpty);
+  while (todo) {
+    const int l = static_cast<int>(__builtin_ctzll(todo));
+    const uint32_t K0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(K), l));
+    const bool mine = K == K0 && ((todo >> lane) & 1ull) != 0ull;
+    const unsigned long long same = __ballot(mine);
+    uint32_t slot = 0u;
+    if (lane == l) {
+      slot = pair_slot(hkey, cb.logT, K0);
+      atomicAdd(cb.hcnt + static_cast<size_t>(frame) * cb.T + slot, static_cast<uint32_t>(__popcll(same)));
+    }
+    slot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(slot), l));
+    if (mine) {
+      unsigned long long* hb = cb.hbest + static_cast<size_t>(frame) * cb.T + slot;
+      if (val < __hip_atomic_load(hb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(hb, val);
+    }
+    todo &= ~same;
+  }
+  (void)lt_mask;
 }
 
+// grid (ceil(T / 256), B): every pair counts for its core
+__global__ __launch_bounds__(256) void k_pair_count(Params prm, CoreBufs cb) {
+  const int frame = blockIdx.y;
+  const int t = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
+  if (t >= cb.T) return;
+  const uint32_t K = cb.hkey[static_cast<size_t>(frame) * cb.T + t];
+  if (K == kPairEmpty) return;
+  atomicAdd(cb.npairs + static_cast<size_t>(frame) * prm.C + (K >> kPairBinBits), 1u);
+}
+
+// grid (ceil(C / 256), B): room for every core's pairs and one-way edges
 __global__ __launch_bounds__(256) void k_core_alloc(Params prm, CoreBufs cb) {
   const int frame = blockIdx.y;
   const int c = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
   if (c >= prm.C) return;
   const size_t fo = static_cast<size_t>(frame) * prm.C;
-  const uint32_t sz = cb.csize[fo + c] & kCoreSizeMask;
-  if (sz == 0u) return;  // (only roots of planar cores have a size)
-  // (after k_core_flatten a cell's parent may still be an intermediate ancestor: its root is found again where needed)
-  cb.cstart[fo + c] = atomicAdd(cb.cursor + frame, sz);
+  if (cb.csize[fo + c] == 0u) return;  // (only roots of planar cores have a size)
+  cb.pstart[fo + c] = atomicAdd(cb.cursor + 4 * frame, cb.npairs[fo + c]);
+  const uint32_t ne = cb.noe[fo + c];
+  if (ne) cb.oestart[fo + c] = atomicAdd(cb.cursor + 4 * frame + 1, ne);
 }
 
-__global__ __launch_bounds__(256) void k_core_scatter(Params prm, CoreBufs cb) {
+// grid (ceil(max(T, C) / 256), B): pairs into their core's list + their sort key; one-way edges into their core's list
+__global__ __launch_bounds__(256) void k_pair_scatter(Params prm, CoreBufs cb) {
   const int frame = blockIdx.y;
-  const int c = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
-  if (c >= prm.C) return;
+  const int i = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
   const size_t fo = static_cast<size_t>(frame) * prm.C;
-  const uint32_t m = cb.meta[fo + c];
-  if (!(m & F_UNASSIGNED)) return;
-  const uint32_t r = cc_find(cb.parent + fo, static_cast<uint32_t>(c));
-  cb.parent[fo + c] = r;  // (every cell's own entry: its root, final)
-  const uint32_t pos = cb.cstart[fo + r] + atomicAdd(cb.cfill + fo + r, 1u);
-  cb.corecells[fo + pos] = static_cast<uint32_t>(c) | ((m >> META_BIN_SHIFT) << kCellBits);
+  if (i < cb.T) {
+    const size_t to = static_cast<size_t>(frame) * cb.T + i;
+    const uint32_t K = cb.hkey[to];
+    if (K != kPairEmpty) {
+      const uint32_t root = K >> kPairBinBits, bin = K & kPairBinMask;
+      const uint32_t cnt = cb.hcnt[to];
+      const uint32_t j = cb.pstart[fo + root] + atomicAdd(cb.pfill + fo + root, 1u);
+      cb.corepairs[fo + j] = bin | (cnt << kPairBinBits);
+      cb.keys[static_cast<size_t>(frame) * cb.Cpad + j] = (static_cast<unsigned long long>(bin) << kKeyBinShift) | cb.hbest[to];
+      atomicAdd(cb.histg + static_cast<size_t>(frame) * (prm.hist_B * prm.hist_B) + bin, cnt);
+    }
+  }
+  if (i < prm.C) {
+    const uint32_t m = cb.meta[fo + i];
+    const uint32_t ow = (m & F_UNASSIGNED) ? (((m >> 2) & ~(m >> 8)) & 0xFu) : 0u;
+    if (ow) {
+      const uint32_t r = cb.parent[fo + i];
+#pragma unroll
+      for (int dir = 0; dir < 4; ++dir)
+        if ((ow >> dir) & 1u) {
+          const int v = i + (dir == 0 ? -prm.nh : (dir == 1 ? prm.nh : (dir == 2 ? -1 : 1)));
+          const uint32_t rv = cb.parent[fo + v];
+          if (rv != r) cb.oedges[4 * fo + cb.oestart[fo + r] + atomicAdd(cb.oefill + fo + r, 1u)] = rv;
+        }
+    }
+  }
 }
 
-// sorted keys (dpx_binsort.h) -> order64[B][C]: the seed lists with each cell's core (start, size, one-way-out) beside
-// it, and bin_off[B][nb + 1] as k_sort_lists writes them
-__global__ __launch_bounds__(256) void k_sort_lists64(Params prm, const unsigned long long* __restrict__ keys, int Cpad, CoreBufs cb,
-                                                      unsigned long long* __restrict__ order64, uint32_t* __restrict__ bin_off) {
+// sorted keys (dpx_binsort.h) -> lists[B][C]: the seed lists, one entry per pair — {leader cell | one-way-out << 31, core ID,
+// pairs of the core, cells of the core} — and bin_off[B][nb + 1] as k_sort_lists writes them
+__global__ __launch_bounds__(256) void k_sort_lists_pairs(Params prm, const unsigned long long* __restrict__ keys, int Cpad, CoreBufs cb,
+                                                          uint4* __restrict__ lists, uint32_t* __restrict__ bin_off) {
   const long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
   const long long total = static_cast<long long>(prm.batch) * Cpad;
   if (i >= total) return;
@@ -192,53 +299,55 @@ __global__ __launch_bounds__(256) void k_sort_lists64(Params prm, const unsigned
     const size_t fo = static_cast<size_t>(frame) * prm.C;
     const uint32_t cell = static_cast<uint32_t>(key & kCellMask);
     const uint32_t r = cb.parent[fo + cell];
-    const uint32_t sz = cb.csize[fo + r], st = cb.cstart[fo + r];
-    order64[fo + pos] = static_cast<unsigned long long>(cell) | (static_cast<unsigned long long>(st) << kE64StartShift) |
-                        (static_cast<unsigned long long>(sz & kCoreSizeMask) << kE64SizeShift) |
-                        (static_cast<unsigned long long>(sz >> 31) << kE64OutShift);
+    lists[fo + pos] = make_uint4(cell | (cb.noe[fo + r] ? kCoreOut : 0u), cb.pstart[fo + r], cb.npairs[fo + r], cb.csize[fo + r]);
   }
 }
 
 // ---- the sequence of grows --------------------------------------------------------------------------------------------
 struct SimBufs {
-  const unsigned long long* order64;  // [B][C]
+  const uint4* lists;                 // [B][C]  seed lists (k_sort_lists_pairs)
   const uint32_t* bin_off;            // [B][nb + 1]
-  const uint32_t* abits0;             // [B][Wb]
-  const uint32_t* corecells;          // [B][C]
-  const uint32_t* meta;               // [B][C]  (one-way edges of irregular grows)
+  const uint32_t* histg;              // [B][nb]
+  const uint32_t* corepairs;          // [B][C]
+  const uint32_t* oedges;             // [B][4C]
   const uint32_t* parent;             // [B][C]
-  const uint32_t* csize;
-  const uint32_t* cstart;
-  uint32_t* cgrow;                    // [B][C]  by core start: grow + 1
+  const uint32_t* csize;              // per root
+  const uint32_t* npairs;
+  const uint32_t* pstart;
+  const uint32_t* noe;
+  const uint32_t* oestart;
+  const uint32_t* cursor;             // [B][4]: pairs, one-way edges, planar cells of the frame
+  uint32_t* cgrow;                    // [B][C]  by core ID: grow + 1
   uint32_t* worklist;                 // [B][C]  cores of an irregular grow (roots)
   uint4* cand_grow;                   // [B][pcap]  grow index, queue range [y, z), seed | kCandWide
   uint32_t* biglist;                  // [B][pcap]  candidate indices of the grows k_order gives a whole wave
   int* hdr_out;                       // [B][48] the header the tail launch starts from (k_regions2 hdr[] layout) + counts
   unsigned long long* dbg;            // diagnostic: [B][kDbgSlots]
-  int pcap, Wb;
+  int pcap;
 };
 constexpr uint32_t kCandWide = 0x80000000u;  // cand_grow.w: the grow is ordered by a whole wave (it is in biglist)
 // hdr_out words: 0 planar cells, 1 activations (queue tail), 2 grows, 3 candidates, 4 entries of biglist
 constexpr int kHdrBig = 4;
+constexpr int kWin = 4;  // seed-list entries per bin kept in LDS
 
 struct S3Layout {
-  uint32_t hist, cursor, bin_start, cand, bclaim, nzlist, evb, rrec, rsrc, abits, end;
+  uint32_t hist, cursor, lo, hi, bclaim, nzlist, evb, rrec, rsrc, win, cbits, end;
 };
-__host__ __device__ inline S3Layout s3_layout(int nb, int Wb) {
+__host__ __device__ inline S3Layout s3_layout(int nb, int C) {
   S3Layout L{};
   uint32_t o = 256;  // header words
   L.hist = o; o += 4u * nb;
   L.cursor = o; o += 4u * nb;
-  L.bin_start = o; o += 4u * (nb + 2);
-  o = (o + 7u) & ~7u;
-  L.cand = o; o += 8u * nb;
+  L.lo = o; o += 4u * nb;
+  L.hi = o; o += 4u * nb;
   L.bclaim = o; o += 4u * nb;
   L.nzlist = o; o += 2u * nb;
-  o = (o + 7u) & ~7u;
+  o = (o + 15u) & ~15u;
   L.evb = o; o += 128;
   L.rrec = o; o += 64 * 8;
   L.rsrc = o; o += 64;
-  L.abits = o; o += 4u * static_cast<uint32_t>(Wb);
+  L.win = o; o += 16u * kWin * static_cast<uint32_t>(nb);
+  L.cbits = o; o += 4u * static_cast<uint32_t>((C + 31) / 32 + 1);
   L.end = (o + 15u) & ~15u;
   return L;
 }
@@ -250,56 +359,51 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
   __builtin_amdgcn_s_setprio(DPX_REGIONS_PRIO);
 #endif
   const unsigned long long t_start = DBG ? static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) : 0ull;
-  unsigned long long n_rounds = 0, n_wide = 0, n_irreg = 0, n_scan64 = 0, n_multi = 0, n_skip = 0;
+  unsigned long long n_rounds = 0, n_wide = 0, n_irreg = 0, n_refill = 0, n_multi = 0, n_skip = 0, t_setup = 0;
   const int frame = blockIdx.x, lane = threadIdx.x;
-  const int C = prm.C, nh = prm.nh;
+  const int C = prm.C;
   const int nb = prm.hist_B * prm.hist_B;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   extern __shared__ __align__(16) unsigned char smem[];
-  const S3Layout lay = s3_layout(nb, sb.Wb);
+  const S3Layout lay = s3_layout(nb, C);
   int* hdr = reinterpret_cast<int*>(smem);
   int* hist = reinterpret_cast<int*>(smem + lay.hist);
-  int* cursor = reinterpret_cast<int*>(smem + lay.cursor);          // END of bin b's list
-  uint32_t* bin_start = reinterpret_cast<uint32_t*>(smem + lay.bin_start);  // first possibly live entry
-  unsigned long long* candc = reinterpret_cast<unsigned long long*>(smem + lay.cand);  // verified head entry of the bin's list
+  int* cursor = reinterpret_cast<int*>(smem + lay.cursor);  // END of bin b's list
+  int* lo = reinterpret_cast<int*>(smem + lay.lo);          // first possibly live entry of bin b's list
+  int* hi = reinterpret_cast<int*>(smem + lay.hi);          // entries [lo, hi) are in the bin's window (slot = index & 3)
   uint32_t* bclaim = reinterpret_cast<uint32_t*>(smem + lay.bclaim);
   uint16_t* nzlist = reinterpret_cast<uint16_t*>(smem + lay.nzlist);
   uint16_t* evb = reinterpret_cast<uint16_t*>(smem + lay.evb);
   uint2* rrec = reinterpret_cast<uint2*>(smem + lay.rrec);
   uint8_t* rsrc = smem + lay.rsrc;
-  uint32_t* abits = reinterpret_cast<uint32_t*>(smem + lay.abits);
+  uint4* win = reinterpret_cast<uint4*>(smem + lay.win);
+  uint32_t* cbits = reinterpret_cast<uint32_t*>(smem + lay.cbits);  // bit (core ID): the core is unassigned
 
   const size_t fo = static_cast<size_t>(frame) * C;
-  const unsigned long long* order = sb.order64 + fo;
-  const uint32_t* corecells = sb.corecells + fo;
+  const uint4* lists = sb.lists + fo;
+  const uint32_t* corepairs = sb.corepairs + fo;
   uint32_t* cgrow = sb.cgrow + fo;
   uint4* cand_grow = sb.cand_grow + static_cast<size_t>(frame) * sb.pcap;
   uint32_t* biglist = sb.biglist + static_cast<size_t>(frame) * sb.pcap;
-  constexpr unsigned long long kNone = ~0ull;
 
-  // ---- state: histogram and list bounds from the sorted seed lists, planar bitmap, non-empty bins
-  if (lane < 64) hdr[lane] = 0;
+  // ---- state: histogram, list bounds, every core alive, non-empty bins
+  hdr[lane] = 0;
   {
     const uint32_t* bo = sb.bin_off + static_cast<size_t>(frame) * (nb + 1);
+    const uint32_t* hg = sb.histg + static_cast<size_t>(frame) * nb;
     for (int b = lane; b < nb; b += 64) {
       const uint32_t s0 = bo[b], s1 = bo[b + 1];
-      hist[b] = static_cast<int>(s1 - s0);
-      bin_start[b] = s0;
+      const int hv = static_cast<int>(hg[b]);
+      hist[b] = hv;
+      lo[b] = static_cast<int>(s0);
+      hi[b] = static_cast<int>(s0);
       cursor[b] = static_cast<int>(s1);
-      candc[b] = kNone;
       bclaim[b] = 0xFFFFFFFFu;
     }
+    const int npair_total = static_cast<int>(sb.cursor[4 * frame]);
+    for (int w = lane; w < (npair_total + 31) / 32 + 1; w += 64) cbits[w] = 0xFFFFFFFFu;
   }
-  int planar_cnt = 0;
-  {
-    const uint32_t* a0 = sb.abits0 + static_cast<size_t>(frame) * sb.Wb;
-    for (int w = lane; w < sb.Wb; w += 64) {
-      const uint32_t v = a0[w];
-      abits[w] = v;
-      planar_cnt += __popc(v);
-    }
-  }
-  const int planar_total = wave_sum(planar_cnt);
+  const int planar_total = static_cast<int>(sb.cursor[4 * frame + 2]);
   wave_sync();
   {
     int nz = 0;
@@ -313,8 +417,8 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
     if (lane == 0) hdr[5] = nz;
   }
   wave_sync();
-  auto alive = [&](uint32_t cell) { return ((abits[cell >> 5] >> (cell & 31u)) & 1u) != 0u; };
-  auto kill = [&](uint32_t cell) { atomicAnd(&abits[cell >> 5], ~(1u << (cell & 31u))); };
+  auto alive = [&](uint32_t id) { return ((cbits[id >> 5] >> (id & 31u)) & 1u) != 0u; };
+  if (DBG) t_setup = static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - t_start;
 
   int remaining = planar_total;
   int tail = 0, ngrow = 0, ncand = 0, nbig = 0;
@@ -421,75 +525,58 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
       cont_level = bv;
     }
     const int bs = b >= 0 ? b : 0;
-    // ---- seeds: the first live entry of each bin's list (sorted by mse, then cell id: plane_extractor.cpp:309-316)
-    int pos = static_cast<int>(bin_start[bs]);
+    // ---- seeds: the first live entry of each bin's list (one entry per (core, bin) pair, sorted by the leader's mse, then
+    // cell id: plane_extractor.cpp:309-316).  The next few entries of every list sit in an LDS window; a list is read from
+    // global memory only when its window runs empty.
+    int pos = lo[bs];
+    int whi = hi[bs];
     const int lend = cursor[bs];
-    unsigned long long e64 = candc[bs];
-    bool need = part && (e64 == kNone || !alive(static_cast<uint32_t>(e64) & kCellMask));
-    bool broken = false;
-    if (__ballot(need)) {
+    uint4 e = make_uint4(0u, 0u, 0u, 0u);
+    bool need = part, broken = false;
+    for (;;) {
       if (need) {
-        if (e64 != kNone) ++pos;  // the cached entry died (taken by another bin's grow)
-        if (pos >= lend) {        // cannot happen (a bin's count is the number of live entries of its list): safety net
+#pragma unroll
+        for (int k = 0; k < kWin; ++k)
+          if (need && pos < whi) {
+            const uint4 x = win[bs * kWin + (pos & (kWin - 1))];
+            if (alive(x.y)) {
+              e = x;
+              need = false;
+            } else {
+              ++pos;
+            }
+          }
+      }
+      if (!__ballot(need)) break;
+      if (DBG) ++n_refill;
+      if (need) {  // (pos == whi here: the window is used up)
+        if (pos >= lend) {  // cannot happen (a bin's count is the number of its live cells, every one behind a live leader)
           broken = true;
           need = false;
         } else {
-          const int i1 = pos + 1 < lend ? pos + 1 : lend - 1, i2 = pos + 2 < lend ? pos + 2 : lend - 1, i3 = pos + 3 < lend ? pos + 3 : lend - 1;
-          const unsigned long long e0 = order[pos], e1 = order[i1], e2 = order[i2], e3 = order[i3];
-          if (alive(static_cast<uint32_t>(e0) & kCellMask)) { e64 = e0; need = false; }
-          else if (pos + 1 < lend && alive(static_cast<uint32_t>(e1) & kCellMask)) { e64 = e1; pos += 1; need = false; }
-          else if (pos + 2 < lend && alive(static_cast<uint32_t>(e2) & kCellMask)) { e64 = e2; pos += 2; need = false; }
-          else if (pos + 3 < lend && alive(static_cast<uint32_t>(e3) & kCellMask)) { e64 = e3; pos += 3; need = false; }
-          else pos += 4;
+#pragma unroll
+          for (int k = 0; k < kWin; ++k)
+            if (pos + k < lend) win[bs * kWin + ((pos + k) & (kWin - 1))] = lists[pos + k];
+          whi = pos + kWin < lend ? pos + kWin : lend;
         }
       }
-      unsigned long long nm = __ballot(need);
-      while (nm) {  // the wave together, 64 entries per step: behind a large grow a list's front is dead for a long stretch
-        const int l = static_cast<int>(__builtin_ctzll(nm));
-        nm &= nm - 1ull;
-        int p = __builtin_amdgcn_readlane(pos, l);
-        const int e = __builtin_amdgcn_readlane(lend, l);
-        unsigned long long found = kNone;
-        while (p < e) {
-          const int i = p + lane;
-          unsigned long long ce = 0ull;
-          bool al = false;
-          if (i < e) {
-            ce = order[i];
-            al = alive(static_cast<uint32_t>(ce) & kCellMask);
-          }
-          const unsigned long long am = __ballot(al);
-          if (DBG) ++n_scan64;
-          if (am) {
-            const int first = static_cast<int>(__builtin_ctzll(am));
-            const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(ce)), first));
-            const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(ce >> 32)), first));
-            found = (static_cast<unsigned long long>(hi) << 32) | lo;
-            p += first;
-            break;
-          }
-          p += 64;
-        }
-        if (lane == l) {
-          need = false;
-          pos = p;
-          if (found == kNone) broken = true;
-          else e64 = found;
-        }
-      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
     }
     if (__ballot(broken)) break;
-    const uint32_t cell = static_cast<uint32_t>(e64) & kCellMask;
-    const uint32_t cstart_ = static_cast<uint32_t>(e64 >> kE64StartShift) & kCellMask;
-    const int csz = part ? static_cast<int>(static_cast<uint32_t>(e64 >> kE64SizeShift) & kCoreSizeMask) : 0;
-    const bool cout_ = ((e64 >> kE64OutShift) & 1ull) != 0ull;
+    const uint32_t cell = e.x & kCellMask;
+    const bool cout_ = (e.x & kCoreOut) != 0u;
+    const uint32_t cid = e.y;
+    const int np = part ? static_cast<int>(e.z) : 0;
+    const int csz = part ? static_cast<int>(e.w) : 0;
     // ---- which events fire.  A grow from a core without a one-way edge out takes exactly that core, so events interact
     // only through the histogram: a bin that loses a cell to a lower lane THAT FIRES is no longer at the level when its
-    // turn comes and is skipped (that covers a lower lane taking this lane's seed too).  Every cell of a multi-cell core
-    // is an ITEM, one wave lane each: it claims its bin with min(source lane), and on commit leaves the bitmap and the
-    // histogram.  Large cores and cores with a one-way edge out stop the round and fire alone ("wide").
-    bool complete = part && csz <= kItemMax && !cout_;
-    int cnt = (complete && csz > 1) ? csz : 0;
+    // turn comes and is skipped (that covers a lower lane taking this lane's seed too — the seed's bin is this lane's).
+    // Every pair of a multi-bin core is an ITEM, one wave lane each: it claims its bin with min(source lane) and on commit
+    // takes its cells out of the histogram.  Cores of more than kItemMax bins and cores with a one-way edge out stop the
+    // round and fire alone ("wide").
+    bool complete = part && np <= kItemMax && !cout_;
+    int cnt = (complete && np > 1) ? np : 0;
     const int incl_items = wave_incl_scan_i32(cnt);
     if (cnt > 0 && incl_items > 64) {  // (any give-up is exact: the event waits for a later round or fires alone)
       complete = false;
@@ -498,13 +585,12 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
     const unsigned long long multi = __ballot(cnt > 0);
     uint32_t lowb = 0xFFFFFFFFu;
     bool it_ok = false;
-    int it_src = 0, it_bin = -1;
-    uint32_t it_cell = 0;
+    int it_src = 0, it_bin = -1, it_cnt = 0;
     if (multi) {
       if (DBG) ++n_multi;
       const int off = incl_items - cnt;
       const int nitems = static_cast<int>(wave_max_u32(cnt > 0 ? static_cast<uint32_t>(incl_items) : 0u));
-      rrec[lane] = make_uint2(cstart_, static_cast<uint32_t>(off));
+      rrec[lane] = make_uint2(cid, static_cast<uint32_t>(off));
 #pragma unroll
       for (int i = 0; i < kItemMax; ++i)
         if (i < cnt) rsrc[off + i] = static_cast<uint8_t>(lane);
@@ -514,18 +600,17 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
       if (it_ok) {
         it_src = static_cast<int>(rsrc[lane]);
         const uint2 r = rrec[it_src];
-        const uint32_t ce = corecells[r.x + static_cast<uint32_t>(lane) - r.y];
-        it_cell = ce & kCellMask;
-        const int bn = static_cast<int>(ce >> kCellBits);
-        it_bin = (bn >= 1 && bn - 1 < nb) ? bn - 1 : -1;
-        if (it_bin >= 0) atomicMin(&bclaim[it_bin], static_cast<uint32_t>(it_src));
+        const uint32_t pr = corepairs[r.x + static_cast<uint32_t>(lane) - r.y];
+        it_bin = static_cast<int>(pr & kPairBinMask);
+        it_cnt = static_cast<int>(pr >> kPairBinBits);
+        atomicMin(&bclaim[it_bin], static_cast<uint32_t>(it_src));
       }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
       if (part) lowb = bclaim[bs];
       asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
-      if (it_ok && it_bin >= 0) bclaim[it_bin] = 0xFFFFFFFFu;  // clean for the next round
+      if (it_ok) bclaim[it_bin] = 0xFFFFFFFFu;  // clean for the next round
     }
     const bool flag = part && (!complete || lowb < static_cast<uint32_t>(lane));
     unsigned long long fl = __ballot(flag), skipped = 0ull;
@@ -544,7 +629,7 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
         stop = t;  // the lowest claimant was itself skipped — what the other claimants did is unknown: next round
         break;
       }
-      stop = t;  // a large or irregular grow whose bin nobody touched: it fires now, alone
+      stop = t;  // a grow that is not handled in a round and whose bin nobody touched: it fires now, alone
       stop_wide = true;
       break;
     }
@@ -553,39 +638,35 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
     const bool cmt = ((cm >> lane) & 1ull) != 0ull;
     if (part) {
       const bool used = cmt || (stop_wide && lane == stop);
-      bin_start[bs] = static_cast<uint32_t>(used ? pos + 1 : pos);
-      candc[bs] = used ? kNone : e64;
+      lo[bs] = used ? pos + 1 : pos;
+      hi[bs] = whi;
     }
     if (cm) {
       const int grank = static_cast<int>(__popcll(cm & lt_mask));
       const int ncm = static_cast<int>(__popcll(cm));
       const int myn = cmt ? csz : 0;
-      int base, total;
-      if (!(multi & cm)) {  // (uniform) one cell each
-        base = tail + grank;
-        total = ncm;
-      } else {
-        const int incl = wave_incl_scan_i32(myn);
-        total = __builtin_amdgcn_readlane(incl, 63);
-        base = tail + incl - myn;
+      const int incl = wave_incl_scan_i32(myn);
+      const int total = __builtin_amdgcn_readlane(incl, 63);
+      const int base = tail + incl - myn;
+      if (cmt) {
+        atomicAnd(&cbits[cid >> 5], ~(1u << (cid & 31u)));  // the core is assigned
+        if (np == 1) atomicSub(&hist[bs], csz);              // hist.removePoint for each of its cells
       }
-      if (cmt && csz == 1) {
-        kill(cell);
-        atomicSub(&hist[bs], 1);  // hist.removePoint
-      }
-      if ((multi & cm) && it_ok && ((cm >> it_src) & 1ull) != 0ull) {
-        kill(it_cell);
-        if (it_bin >= 0) atomicSub(&hist[it_bin], 1);
-      }
+      if ((multi & cm) && it_ok && ((cm >> it_src) & 1ull) != 0ull) atomicSub(&hist[it_bin], it_cnt);
       // cells_to_merge.size() < min_region_growing_cells_activated (size_t comparison, plane_extractor.cpp:329)
       const bool want_cand = cmt && !(static_cast<unsigned long long>(csz) < static_cast<unsigned long long>(static_cast<long long>(prm.min_cells)));
       const unsigned long long wantmask = __ballot(want_cand);
       if (wantmask) {
         const int crank = static_cast<int>(__popcll(wantmask & lt_mask));
-        if (want_cand && ncand + crank < sb.pcap) {
-          cand_grow[ncand + crank] = make_uint4(static_cast<uint32_t>(ngrow + grank), static_cast<uint32_t>(base), static_cast<uint32_t>(base + csz), cell);
-          cgrow[cstart_] = static_cast<uint32_t>(ngrow + grank + 1);
+        const bool have = want_cand && ncand + crank < sb.pcap;
+        const bool bigc = have && csz > kItemMax;  // more cells than a lane orders on its own: a wave's work in k_order
+        const unsigned long long bigmask = __ballot(bigc);
+        if (have) {
+          cand_grow[ncand + crank] = make_uint4(static_cast<uint32_t>(ngrow + grank), static_cast<uint32_t>(base), static_cast<uint32_t>(base + csz), cell | (bigc ? kCandWide : 0u));
+          cgrow[cid] = static_cast<uint32_t>(ngrow + grank + 1);
+          if (bigc) biglist[nbig + static_cast<int>(__popcll(bigmask & lt_mask))] = static_cast<uint32_t>(ncand + crank);
         }
+        nbig += static_cast<int>(__popcll(bigmask));
         const int nwant = static_cast<int>(__popcll(wantmask));
         ncand += nwant < sb.pcap - ncand ? nwant : (sb.pcap - ncand > 0 ? sb.pcap - ncand : 0);
       }
@@ -596,71 +677,60 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     if (!stop_wide) continue;
-    // ---- the stopping event fires alone: every cell of its core(s) leaves the bitmap and the histogram, 64 per step
+    // ---- the stopping event fires alone: the pairs of its core(s) leave the histogram, 64 per step
     if (DBG) ++n_wide;
     const uint32_t wcell = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cell), stop));
-    const uint32_t wstart = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cstart_), stop));
+    const uint32_t wcid = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cid), stop));
+    const int wnp = __builtin_amdgcn_readlane(np, stop);
     const int wsz = __builtin_amdgcn_readlane(csz, stop);
     const bool wout = ((__ballot(cout_) >> stop) & 1ull) != 0ull;
-    int gsize = 0;
-    auto take_core = [&](uint32_t st, int sz, uint32_t root, bool follow) {
-      for (int i = 0; i < sz; i += 64) {
-        const bool in = i + lane < sz;
-        const uint32_t ce = in ? corecells[st + static_cast<uint32_t>(i + lane)] : 0u;
-        const uint32_t cl = ce & kCellMask;
-        if (in) {
-          kill(cl);
-          const int bn = static_cast<int>(ce >> kCellBits);
-          if (bn >= 1 && bn - 1 < nb) atomicSub(&hist[bn - 1], 1);
-          if (follow) {  // one-way edges out of this cell: their targets' cores join the grow if they are still alive
-            const uint32_t m = sb.meta[fo + cl];
-            const uint32_t ow = ((m >> 2) & ~(m >> 8)) & 0xFu;
-#pragma unroll
-            for (int dir = 0; dir < 4; ++dir)
-              if ((ow >> dir) & 1u) {
-                const int v = static_cast<int>(cl) + (dir == 0 ? -nh : (dir == 1 ? nh : (dir == 2 ? -1 : 1)));
-                const uint32_t rv = sb.parent[fo + v];
-                if (rv != root) {
-                  // a core is alive as long as its root's bit is set; whoever clears it has found the core
-                  const uint32_t bit = 1u << (rv & 31u);
-                  const uint32_t old = atomicAnd(&abits[rv >> 5], ~bit);
-                  if (old & bit) sb.worklist[fo + static_cast<uint32_t>(atomicAdd(&hdr[8], 1))] = rv;
-                }
-              }
-          }
-        }
+    auto take_pairs = [&](uint32_t pst, int n) {
+      for (int i = lane; i < n; i += 64) {
+        const uint32_t pr = corepairs[pst + static_cast<uint32_t>(i)];
+        atomicSub(&hist[pr & kPairBinMask], static_cast<int>(pr >> kPairBinBits));
       }
-      gsize += sz;
     };
-    if (!wout) {
-      take_core(wstart, wsz, 0u, false);
-    } else {
+    int gsize = wsz;
+    int nwl = 0;
+    if (lane == 0) atomicAnd(&cbits[wcid >> 5], ~(1u << (wcid & 31u)));
+    take_pairs(wcid, wnp);
+    if (wout) {
       if (DBG) ++n_irreg;
-      // the cores reachable from the seed's core over one-way edges, in any order (the SET is what the sequence needs)
+      // the cores reachable from the seed's core over one-way edges among the cores still unassigned, in any order (the
+      // SET is what the sequence needs; k_order finds the activation order)
+      uint32_t* wl = sb.worklist + fo;
       const uint32_t root0 = sb.parent[fo + wcell];
       if (lane == 0) {
         hdr[8] = 1;
-        sb.worklist[fo] = root0;
-        kill(root0);
+        wl[0] = root0;
       }
       wave_sync();
       for (int wi = 0;; ++wi) {
-        const int nwl = *static_cast<volatile int*>(&hdr[8]);
+        nwl = *static_cast<volatile int*>(&hdr[8]);
         if (wi >= nwl) break;
-        const uint32_t r = __hip_atomic_load(sb.worklist + fo + wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t st = sb.cstart[fo + r];
-        const int sz = static_cast<int>(sb.csize[fo + r] & kCoreSizeMask);
-        take_core(st, sz, r, true);
+        const uint32_t r = __hip_atomic_load(wl + wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t ne = sb.noe[fo + r], es = sb.oestart[fo + r];
+        if (wi > 0) {  // (the seed's core is accounted for above)
+          gsize += static_cast<int>(sb.csize[fo + r]);
+          take_pairs(sb.pstart[fo + r], static_cast<int>(sb.npairs[fo + r]));
+        }
+        for (uint32_t i = lane; i < ne; i += 64) {
+          const uint32_t rv = sb.oedges[4 * fo + es + i];
+          const uint32_t id = sb.pstart[fo + rv];
+          // a core is unassigned as long as its bit is set; whoever clears it has found the core
+          const uint32_t bit = 1u << (id & 31u);
+          const uint32_t old = atomicAnd(&cbits[id >> 5], ~bit);
+          if (old & bit) wl[atomicAdd(&hdr[8], 1)] = rv;
+        }
         wave_sync();
       }
     }
     const bool is_cand = !(static_cast<unsigned long long>(gsize) < static_cast<unsigned long long>(static_cast<long long>(prm.min_cells))) && ncand < sb.pcap;
     if (is_cand) {
       if (!wout) {
-        if (lane == 0) cgrow[wstart] = static_cast<uint32_t>(ngrow + 1);
+        if (lane == 0) cgrow[wcid] = static_cast<uint32_t>(ngrow + 1);
       } else {
-        const int nwl = hdr[8];
-        for (int i = lane; i < nwl; i += 64) cgrow[sb.cstart[fo + sb.worklist[fo + i]]] = static_cast<uint32_t>(ngrow + 1);
+        for (int i = lane; i < nwl; i += 64) cgrow[sb.pstart[fo + sb.worklist[fo + i]]] = static_cast<uint32_t>(ngrow + 1);
       }
       if (lane == 0) {
         cand_grow[ncand] = make_uint4(static_cast<uint32_t>(ngrow), static_cast<uint32_t>(tail), static_cast<uint32_t>(tail + gsize), wcell | kCandWide);
@@ -688,9 +758,11 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
   }
   if (DBG && sb.dbg && lane == 0) {
     unsigned long long* d = sb.dbg + static_cast<size_t>(frame) * kDbgSlots;
+    d[0] = t_setup;
     d[1] = static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - t_start;
     d[11] = n_rounds; d[13] = static_cast<unsigned long long>(ngrow); d[14] = static_cast<unsigned long long>(ncand);
-    d[15] = static_cast<unsigned long long>(tail); d[19] = n_scan64; d[21] = n_wide; d[22] = n_skip; d[23] = n_irreg; d[28] = n_multi;
+    d[15] = static_cast<unsigned long long>(tail); d[19] = n_refill; d[21] = n_wide; d[22] = n_skip; d[23] = n_irreg; d[28] = n_multi;
+    d[29] = static_cast<unsigned long long>(sb.cursor[4 * frame]); d[30] = static_cast<unsigned long long>(nbig);
   }
 }
 
@@ -703,7 +775,7 @@ __global__ __launch_bounds__(256) void k_cellgrow(Params prm, CoreBufs cb) {
   const uint32_t m = cb.meta[fo + c];
   uint32_t q = 0u;
   if (m & F_UNASSIGNED) {
-    const uint32_t g1 = cb.cgrow[fo + cb.cstart[fo + cb.parent[fo + c]]];
+    const uint32_t g1 = cb.cgrow[fo + cb.pstart[fo + cb.parent[fo + c]]];
     q = (g1 << 4) | ((m >> 8) & 0xFu);
   }
   cb.cellq[fo + c] = q;
@@ -730,6 +802,7 @@ constexpr int kOrderClaim = 256;  // claim-table slots per wave
 
 template <bool DBG>
 __global__ __launch_bounds__(kOrderWaves * 64) void k_order(Params prm, OrderBufs ob) {
+  const unsigned long long t_start = DBG ? static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) : 0ull;
   const int frame = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int C = prm.C, nh = prm.nh;
@@ -862,6 +935,8 @@ __global__ __launch_bounds__(kOrderWaves * 64) void k_order(Params prm, OrderBuf
       }
     }
   }
+  if (DBG && ob.dbg && lane == 0)
+    atomicMax(ob.dbg + static_cast<size_t>(frame) * kDbgSlots + 2, static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - t_start);
 }
 
 }  // namespace dpx
