@@ -97,6 +97,7 @@ SYMBOLS = {
     "dpx_debug_region_phases": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "dpx_debug_cores_phases": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "dpx_get_options": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
+    "dpx_debug_read_cores": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]),
     "dpx_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
     "dpx_get_kernel_ms": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dpx_time_planefit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.POINTER(C.c_float)]),

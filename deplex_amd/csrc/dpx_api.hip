@@ -1438,6 +1438,36 @@ int dpx_get_options(dpx_handle h, char* buf, int32_t cap) {
   return n;
 }
 
+int64_t dpx_debug_read_cores(dpx_handle h, int32_t which, int32_t frame, void* out, int64_t cap_bytes) {
+  if (!h || !out) return fail(DPX_ERR_ARG, "null argument");
+  if (!h->cores || frame < 0 || frame >= h->max_batch) return fail(DPX_ERR_ARG, "not the core path, or bad frame");
+  DPX_HIP(hipSetDevice(h->device));
+  DPX_HIP(hipStreamSynchronize(h->last_stream));
+  const size_t C = static_cast<size_t>(h->prm.C), f = static_cast<size_t>(frame), nb = static_cast<size_t>(h->prm.hist_B) * h->prm.hist_B;
+  const void* src = nullptr;
+  size_t bytes = 0;
+  switch (which) {
+    case 0: src = h->d_parent + f * C; bytes = C * 4; break;
+    case 1: src = h->d_csize + f * C; bytes = C * 4; break;
+    case 2: src = h->d_npairs + f * C; bytes = C * 4; break;
+    case 3: src = h->d_pstart + f * C; bytes = C * 4; break;
+    case 4: src = h->d_corepairs + f * C; bytes = C * 4; break;
+    case 5: src = h->d_lists + f * C; bytes = C * 16; break;
+    case 6: src = h->d_bin_off + f * (nb + 1); bytes = (nb + 1) * 4; break;
+    case 7: src = h->d_histg + f * nb; bytes = nb * 4; break;
+    case 8: src = h->d_ccursor + f * 4; bytes = 16; break;
+    case 9: src = reinterpret_cast<const int*>(h->d_lds_img) + f * 48; bytes = 192; break;
+    case 10: src = h->d_cand_grow + f * static_cast<size_t>(h->pcap) * 4; bytes = static_cast<size_t>(h->pcap) * 16; break;
+    case 11: src = h->d_gqueue + f * C; bytes = C * 4; break;
+    case 12: src = h->d_cellq + f * C; bytes = C * 4; break;
+    case 13: src = h->d_meta + f * C; bytes = C * 4; break;
+    default: return fail(DPX_ERR_ARG, "unknown array");
+  }
+  if (static_cast<int64_t>(bytes) > cap_bytes) return fail(DPX_ERR_CAPACITY, "buffer too small");
+  DPX_HIP(hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost));
+  return static_cast<int64_t>(bytes);
+}
+
 int dpx_debug_cores_phases(dpx_handle h, int32_t frame, uint64_t* out32) {
   if (!h || !out32) return fail(DPX_ERR_ARG, "null argument");
   if (!h->d_dbg || !h->cores || frame < 0 || frame >= h->max_batch) return fail(DPX_ERR_ARG, "diagnostics not enabled, not the core path, or bad frame");

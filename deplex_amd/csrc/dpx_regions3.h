@@ -66,10 +66,27 @@ struct CoreBufs {
   int T, logT, Cpad;
 };
 
+// Words that several XCDs update with atomics inside one launch (the union-find forest, counters, the pair table) are
+// never written with plain stores: the per-XCD L2s are not coherent with each other, atomics execute at the memory side,
+// and a plain store stays in the storing XCD's L2 as a dirty line whose later write-back would put the old value over an
+// atomic's result (seen as a lost union: one frame in ~100 under load).  Write-through (sc1) stores leave no such line.
 __device__ __forceinline__ uint32_t cc_load(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// root of x; pointers only ever move to lower ids, so a stale read is an older ancestor and the chase still ends
+__device__ __forceinline__ void cc_store(uint32_t* p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void cc_store64(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Lock-free union-find with root hooking.  A root is hooked under a lower id with compare-and-swap — it succeeds only
+// while the node still is a root — and every other write is a compression (atomicMin towards an ancestor).  So a parent
+// pointer, once it leaves its node, only ever moves up that node's own ancestor chain: every value it ever held stays an
+// ancestor.  That is what makes the sc1 loads below safe although the per-XCD L2s are not coherent with each other and may
+// serve a value another XCD has since replaced — a stale parent is merely an older ancestor, and the compare-and-swap itself
+// acts on memory.  (A first version linked with atomicMin on whatever node the find returned and re-united the parent it
+// overwrote: one 4K frame in ~100 came out with a core split in two.  Overwriting a non-root's link makes "was an ancestor"
+// false, and two such repairs can each take the other's dead link for proof that the trees are already joined.)
 __device__ __forceinline__ uint32_t cc_find(uint32_t* p, uint32_t x) {
   uint32_t r = x;
   for (;;) {
@@ -77,7 +94,7 @@ __device__ __forceinline__ uint32_t cc_find(uint32_t* p, uint32_t x) {
     if (q == r) break;
     r = q;
   }
-  while (x != r) {  // compression (atomicMin: never undoes a link made meanwhile)
+  while (x != r) {  // compression
     const uint32_t nx = cc_load(p + x);
     if (nx > r) atomicMin(p + x, r);
     x = nx < x ? nx : r;
@@ -94,9 +111,9 @@ __device__ __forceinline__ void cc_union(uint32_t* p, uint32_t a, uint32_t b) {
       a = b;
       b = t;
     }
-    const uint32_t old = atomicMin(p + a, b);  // link the higher root under the lower one
+    const uint32_t old = atomicCAS(p + a, a, b);  // hook the higher root under the lower node
     if (old == a) return;
-    a = old;  // a was no longer a root: its tree (now under min(old, b)) still has to meet b's
+    a = old;  // a was not a root (any more): go on from its parent
   }
 }
 // slot of pair key K in the frame's table: found or inserted
@@ -119,44 +136,66 @@ __global__ __launch_bounds__(256) void k_core_init(Params prm, CoreBufs cb) {
   const int frame = blockIdx.y;
   const int i = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
   const size_t fo = static_cast<size_t>(frame) * prm.C;
+  // The forest starts with the horizontal runs of each wave's 64 cells already joined: a cell's first parent is the first
+  // cell of its run of symmetric right-edges inside the wave (bit tricks on one ballot) — most of a plane's unions for free.
+  {
+    const uint32_t m = i < prm.C ? cb.meta[fo + i] : 0u;
+    const bool planar = (m & F_UNASSIGNED) != 0u;
+    const bool sym_r = planar && ((m >> 5) & (m >> 11) & 1u) != 0u;  // out- and in-edge R
+    const int lane = threadIdx.x & 63;
+    const unsigned long long E = __ballot(sym_r);                        // bit l: lanes l and l + 1 are joined
+    const unsigned long long gaps = ~E & ((1ull << lane) - 1ull);        // missing joins below this lane
+    const int run_start = gaps ? 64 - static_cast<int>(__builtin_clzll(gaps)) : 0;
+    if (i < prm.C) cc_store(cb.parent + fo + i, static_cast<uint32_t>(planar ? i - lane + run_start : i));
+  }
   if (i < prm.C) {
-    cb.parent[fo + i] = static_cast<uint32_t>(i);
-    cb.csize[fo + i] = 0u;
-    cb.npairs[fo + i] = 0u;
-    cb.pfill[fo + i] = 0u;
-    cb.noe[fo + i] = 0u;
-    cb.oefill[fo + i] = 0u;
-    cb.cgrow[fo + i] = 0u;
+    cc_store(cb.csize + fo + i, 0u);
+    cc_store(cb.npairs + fo + i, 0u);
+    cc_store(cb.pfill + fo + i, 0u);
+    cc_store(cb.noe + fo + i, 0u);
+    cc_store(cb.oefill + fo + i, 0u);
+    cb.cgrow[fo + i] = 0u;  // (written by one wave of one later launch, read by the launch after it: plain)
   }
   if (i < cb.T) {
     const size_t to = static_cast<size_t>(frame) * cb.T + i;
-    cb.hkey[to] = kPairEmpty;
-    cb.hcnt[to] = 0u;
-    cb.hbest[to] = ~0ull;
+    cc_store(cb.hkey + to, kPairEmpty);
+    cc_store(cb.hcnt + to, 0u);
+    cc_store64(cb.hbest + to, ~0ull);
   }
   if (i < cb.Cpad) cb.keys[static_cast<size_t>(frame) * cb.Cpad + i] = ~0ull;
   const int nb = prm.hist_B * prm.hist_B;
-  if (i < nb) cb.histg[static_cast<size_t>(frame) * nb + i] = 0u;
+  if (i < nb) cc_store(cb.histg + static_cast<size_t>(frame) * nb + i, 0u);
   if (i == 0) {
-    cb.cursor[4 * frame] = 0u;
-    cb.cursor[4 * frame + 1] = 0u;
-    cb.cursor[4 * frame + 2] = 0u;
-    cb.order_task[frame] = 0;
+    cc_store(cb.cursor + 4 * frame, 0u);
+    cc_store(cb.cursor + 4 * frame + 1, 0u);
+    cc_store(cb.cursor + 4 * frame + 2, 0u);
+    __hip_atomic_store(cb.order_task + frame, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
-// symmetric edge to the right / lower neighbour -> one union
+// The unions the initial runs do not cover: the right-edge of a wave's last lane, and the down-edges — except a down-edge
+// whose left neighbour is in the same run, has a down-edge too, and whose two lower cells are joined by a right-edge: that
+// union is implied by the left neighbour's.
 __global__ __launch_bounds__(256) void k_core_link(Params prm, CoreBufs cb) {
   const int frame = blockIdx.y;
   const int c = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
-  if (c >= prm.C) return;
   const size_t fo = static_cast<size_t>(frame) * prm.C;
-  const uint32_t m = cb.meta[fo + c];
-  if (!(m & F_UNASSIGNED)) return;
-  const uint32_t sym = ((m >> 2) & (m >> 8)) & 0xFu;  // out-edge and in-edge: dir 0..3 = U, D, L, R
+  const int lane = threadIdx.x & 63;
+  const uint32_t m = c < prm.C ? cb.meta[fo + c] : 0u;
+  const bool planar = (m & F_UNASSIGNED) != 0u;
+  const uint32_t sym = planar ? (((m >> 2) & (m >> 8)) & 0xFu) : 0u;  // out-edge and in-edge: dir 0..3 = U, D, L, R
+  const bool sym_r = (sym & 8u) != 0u, sym_d = (sym & 2u) != 0u;
+  const unsigned long long E = __ballot(sym_r), Dm = __ballot(sym_d);
   uint32_t* p = cb.parent + fo;
-  if (sym & 8u) cc_union(p, static_cast<uint32_t>(c), static_cast<uint32_t>(c + 1));
-  if (sym & 2u) cc_union(p, static_cast<uint32_t>(c), static_cast<uint32_t>(c + prm.nh));
+  if (sym_r && lane == 63) cc_union(p, static_cast<uint32_t>(c), static_cast<uint32_t>(c + 1));
+  if (sym_d) {
+    bool implied = false;
+    if (lane > 0 && ((E >> (lane - 1)) & 1ull) && ((Dm >> (lane - 1)) & 1ull)) {
+      const uint32_t ml = cb.meta[fo + c + prm.nh - 1];  // the cell below the left neighbour
+      implied = ((ml >> 5) & (ml >> 11) & 1u) != 0u;
+    }
+    if (!implied) cc_union(p, static_cast<uint32_t>(c), static_cast<uint32_t>(c + prm.nh));
+  }
 }
 
 // root of every cell; per core: cells, one-way edges out; per (core, bin) pair: cells and leader
@@ -173,7 +212,7 @@ __global__ __launch_bounds__(256) void k_core_flatten(Params prm, CoreBufs cb) {
   int nout = 0;
   if (planar) {
     r = cc_find(p, static_cast<uint32_t>(c));
-    p[c] = r;
+    atomicMin(p + c, r);  // (every cell's own entry: its root — an atomic like every other write to the forest)
     const int bn = static_cast<int>(m >> META_BIN_SHIFT);
     if (bn >= 1 && bn - 1 < prm.hist_B * prm.hist_B) K = (r << kPairBinBits) | static_cast<uint32_t>(bn - 1);
     const uint32_t ow = ((m >> 2) & ~(m >> 8)) & 0xFu;  // one-way out-edges

@@ -274,6 +274,11 @@ int dpx_debug_cores_phases(dpx_handle h, int32_t frame, uint64_t* out32 /* DPX_D
  * variant switches read at dpx_create): ties a result or a timing to its variant.  Returns the length written (without
  * the terminating 0), or a negative error. */
 int dpx_get_options(dpx_handle h, char* buf, int32_t cap);
+/* Diagnostic: copies one intermediate array of the core-based region path for `frame` of the last call into `out`
+ * (which: 0 parent / root per cell [C uint32], 1 csize [C], 2 npairs [C], 3 pstart [C], 4 corepairs [C], 5 seed lists
+ * [C x 4 uint32], 6 bin offsets [bins + 1], 7 per-bin cell counts [bins], 8 cursors [4], 9 sequence header [48 int32],
+ * 10 cand_grow [pcap x 4], 11 queue [C], 12 cellq [C], 13 cell-graph words [C]).  Returns the bytes written. */
+int64_t dpx_debug_read_cores(dpx_handle h, int32_t which, int32_t frame, void* out, int64_t cap_bytes);
 /* Diagnostic (handles created with DPX_RESIDENCY=1 in the environment): average shader-clock lifetime of a frame's
  * workgroup in the three region launches (preparation, grow, tail) over the frames of the last call — how long each
  * holds its LDS while other kernels share the chip. */
