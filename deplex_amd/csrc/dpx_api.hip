@@ -98,6 +98,7 @@ struct dpx_handle_s {
   bool cores = false;
   int core_T = 0, core_logT = 0;              // slots of the pair hash table per frame
   size_t lds3_sim = 0;                        // LDS of the one-wave sequence launch
+  size_t lds3_order = 0;                      // dynamic LDS of the order launch (a huge grow's cells, ring, batch map)
   uint32_t* d_core = nullptr;                 // one allocation for the uint32 arrays below
   uint32_t *d_parent = nullptr, *d_csize = nullptr, *d_npairs = nullptr, *d_pstart = nullptr, *d_pfill = nullptr, *d_noe = nullptr,
            *d_oestart = nullptr, *d_oefill = nullptr, *d_hkey = nullptr, *d_hcnt = nullptr, *d_corepairs = nullptr, *d_oedges = nullptr,
@@ -541,9 +542,9 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
       else hipLaunchKernelGGL(dpx::k_regsim<false>, dim3(batch), dim3(64), h->lds3_sim, s, prm, sb);
       hipLaunchKernelGGL(dpx::k_cellgrow, cell_grid, dim3(256), 0, s, prm, core_bufs(h));
       if (h->d_dbg) {
-        hipLaunchKernelGGL(dpx::k_order<true>, dim3(per_frame, batch), dim3(dpx::kOrderWaves * 64), 0, s, prm, ob);
+        hipLaunchKernelGGL(dpx::k_order<true>, dim3(per_frame, batch), dim3(dpx::kOrderWaves * 64), h->lds3_order, s, prm, ob);
       } else {
-        hipLaunchKernelGGL(dpx::k_order<false>, dim3(per_frame, batch), dim3(dpx::kOrderWaves * 64), 0, s, prm, ob);
+        hipLaunchKernelGGL(dpx::k_order<false>, dim3(per_frame, batch), dim3(dpx::kOrderWaves * 64), h->lds3_order, s, prm, ob);
       }
       if (h->d_dbg) hipLaunchKernelGGL((dpx::k_regions2<0, true, 3>), dim3(batch), dim3(dpx::kTailRT), h->lds2_p3, s, prm, rb, rx);
       else hipLaunchKernelGGL((dpx::k_regions2<0, false, 3>), dim3(batch), dim3(dpx::kTailRT), h->lds2_p3, s, prm, rb, rx);
@@ -1008,13 +1009,14 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
       const int Ci = static_cast<int>(C), nbi = static_cast<int>(nb);
       const dpx::R2Layout l0 = dpx::r2_layout(0, Ci, nbi, nh);
       const bool fits_cores = nb < 4600 && C >= 1 && C < (size_t(1) << dpx::kKeyCellBits) && l0.tail_end <= kLdsLimit &&
-                              dpx::s3_layout(nbi, Ci).end <= kLdsLimit;
+                              dpx::s3_layout(nbi, Ci).end <= kLdsLimit && dpx::order_lds_bytes(Ci) + 8192 <= kLdsLimit;
       if (fits_cores && (force_cores || (!named_old && h->regions_tier != 2))) {
         h->cores = true;
         h->core_logT = 6;
         while ((size_t(1) << h->core_logT) < 2 * C) ++h->core_logT;
         h->core_T = 1 << h->core_logT;
         h->lds3_sim = dpx::s3_layout(nbi, Ci).end;
+        h->lds3_order = dpx::order_lds_bytes(Ci);
         h->regions_tier = 0;
         h->tier0_split = false;
         h->sort_pad = 0;
@@ -1059,7 +1061,7 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
   }
   if (h->cores) {
     const size_t T = static_cast<size_t>(h->core_T);
-    A(dev_alloc(&h->d_core, B * (17 * C + 2 * T + static_cast<size_t>(nb) + 8)));
+    A(dev_alloc(&h->d_core, B * (17 * C + 2 * T + static_cast<size_t>(nb) + 8)));  // (+8: cursors [4], order task counters [2])
     A(dev_alloc(&h->d_hbest, B * T));
     A(dev_alloc(&h->d_lists, B * C));
     if (rc == DPX_OK) {
@@ -1106,6 +1108,11 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->refine_lds)) != hipSuccess)
           rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
     }
+  }
+  if (rc == DPX_OK && h->cores && h->lds3_order + 8192 > 48 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_order<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds3_order)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_order<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds3_order)) != hipSuccess)
+      rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
   }
   if (rc == DPX_OK && h->cores && h->lds3_sim > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regsim<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds3_sim)) != hipSuccess ||

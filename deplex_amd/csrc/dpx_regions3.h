@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256) void k_core_init(Params prm, CoreBufs cb) {
     cc_store(cb.cursor + 4 * frame, 0u);
     cc_store(cb.cursor + 4 * frame + 1, 0u);
     cc_store(cb.cursor + 4 * frame + 2, 0u);
-    __hip_atomic_store(cb.order_task + frame, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(cb.order_task + 2 * frame, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(cb.order_task + 2 * frame + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -365,8 +366,10 @@ struct SimBufs {
   int pcap;
 };
 constexpr uint32_t kCandWide = 0x80000000u;  // cand_grow.w: the grow is ordered by a whole wave (it is in biglist)
-// hdr_out words: 0 planar cells, 1 activations (queue tail), 2 grows, 3 candidates, 4 entries of biglist
-constexpr int kHdrBig = 4;
+// hdr_out words: 0 planar cells, 1 activations (queue tail), 2 grows, 3 candidates, 4 entries of biglist, 5 of them huge
+// (a whole workgroup's work in k_order: they are listed from the END of biglist backwards)
+constexpr int kHdrBig = 4, kHdrHuge = 5;
+constexpr int kHugeMin = 1024;
 constexpr int kWin = 4;  // seed-list entries per bin kept in LDS
 
 struct S3Layout {
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
   if (DBG) t_setup = static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - t_start;
 
   int remaining = planar_total;
-  int tail = 0, ngrow = 0, ncand = 0, nbig = 0;
+  int tail = 0, ngrow = 0, ncand = 0, nbig = 0, nhuge = 0;
   const int nnz = hdr[5];
   int mybin[4];
 #pragma unroll
@@ -698,14 +701,17 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
       if (wantmask) {
         const int crank = static_cast<int>(__popcll(wantmask & lt_mask));
         const bool have = want_cand && ncand + crank < sb.pcap;
-        const bool bigc = have && csz > kItemMax;  // more cells than a lane orders on its own: a wave's work in k_order
-        const unsigned long long bigmask = __ballot(bigc);
+        const bool bigc = have && csz > kItemMax;  // more cells than a lane orders on its own: a wave's work in k_order,
+        const bool hugec = bigc && csz >= kHugeMin;  // or a workgroup's
+        const unsigned long long bigmask = __ballot(bigc && !hugec), hugemask = __ballot(hugec);
         if (have) {
           cand_grow[ncand + crank] = make_uint4(static_cast<uint32_t>(ngrow + grank), static_cast<uint32_t>(base), static_cast<uint32_t>(base + csz), cell | (bigc ? kCandWide : 0u));
           cgrow[cid] = static_cast<uint32_t>(ngrow + grank + 1);
-          if (bigc) biglist[nbig + static_cast<int>(__popcll(bigmask & lt_mask))] = static_cast<uint32_t>(ncand + crank);
+          if (bigc && !hugec) biglist[nbig + static_cast<int>(__popcll(bigmask & lt_mask))] = static_cast<uint32_t>(ncand + crank);
+          if (hugec) biglist[sb.pcap - 1 - nhuge - static_cast<int>(__popcll(hugemask & lt_mask))] = static_cast<uint32_t>(ncand + crank);
         }
         nbig += static_cast<int>(__popcll(bigmask));
+        nhuge += static_cast<int>(__popcll(hugemask));
         const int nwant = static_cast<int>(__popcll(wantmask));
         ncand += nwant < sb.pcap - ncand ? nwant : (sb.pcap - ncand > 0 ? sb.pcap - ncand : 0);
       }
@@ -773,10 +779,12 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
       }
       if (lane == 0) {
         cand_grow[ncand] = make_uint4(static_cast<uint32_t>(ngrow), static_cast<uint32_t>(tail), static_cast<uint32_t>(tail + gsize), wcell | kCandWide);
-        biglist[nbig] = static_cast<uint32_t>(ncand);
+        if (gsize >= kHugeMin) biglist[sb.pcap - 1 - nhuge] = static_cast<uint32_t>(ncand);
+        else biglist[nbig] = static_cast<uint32_t>(ncand);
       }
       ++ncand;
-      ++nbig;
+      if (gsize >= kHugeMin) ++nhuge;
+      else ++nbig;
     }
     tail = __builtin_amdgcn_readfirstlane(tail + gsize);
     ++ngrow;
@@ -793,6 +801,7 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
     v = lane == 2 ? ngrow : v;
     v = lane == 3 ? ncand : v;
     v = lane == kHdrBig ? nbig : v;
+    v = lane == kHdrHuge ? nhuge : v;
     ho[lane] = v;
   }
   if (DBG && sb.dbg && lane == 0) {
@@ -801,7 +810,7 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
     d[1] = static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - t_start;
     d[11] = n_rounds; d[13] = static_cast<unsigned long long>(ngrow); d[14] = static_cast<unsigned long long>(ncand);
     d[15] = static_cast<unsigned long long>(tail); d[19] = n_refill; d[21] = n_wide; d[22] = n_skip; d[23] = n_irreg; d[28] = n_multi;
-    d[29] = static_cast<unsigned long long>(sb.cursor[4 * frame]); d[30] = static_cast<unsigned long long>(nbig);
+    d[29] = static_cast<unsigned long long>(sb.cursor[4 * frame]); d[30] = static_cast<unsigned long long>(nbig) | (static_cast<unsigned long long>(nhuge) << 32);
   }
 }
 
@@ -832,12 +841,20 @@ struct OrderBufs {
   const uint32_t* biglist;  // [B][pcap]
   const int* hdr;           // [B][48]
   uint32_t* queue;          // [B][C]
-  int* task;                // [B] task counter (zeroed by k_core_init's launch sequence)
+  int* task;                // [B][2] task counters: waves' tasks, workgroups' tasks (zeroed by k_core_init)
   unsigned long long* dbg;
   int pcap;
 };
 constexpr int kOrderWaves = 8;
 constexpr int kOrderClaim = 256;  // claim-table slots per wave
+// A HUGE grow (>= kHugeMin cells) takes the whole workgroup: 16 queue slots per wave and step, the grow's cells as one byte
+// each in LDS (bit 0: belongs to the grow and is not activated yet, bits 2..5: in-edges U, D, L, R), the last kHugeRing
+// queue entries in an LDS ring, and duplicates resolved by PULL as in dpx_regions2.h — a lane loses to any in-neighbour of
+// its target that sits earlier in the batch — with the batch's (cell -> slot) map in a small LDS hash table instead of a
+// queue-position array: no global memory inside a step.
+constexpr int kHugeRingBits = 12, kHugeRing = 1 << kHugeRingBits;
+constexpr int kHugeHash = 1024;  // slots of the batch map (a batch holds up to 16 * kOrderWaves cells)
+__host__ __device__ inline size_t order_lds_bytes(int C) { return (static_cast<size_t>(C) + 15u) / 16u * 16u + 4u * kHugeRing + 4u * kHugeHash + 64u; }
 
 template <bool DBG>
 __global__ __launch_bounds__(kOrderWaves * 64) void k_order(Params prm, OrderBufs ob) {
@@ -856,14 +873,111 @@ __global__ __launch_bounds__(kOrderWaves * 64) void k_order(Params prm, OrderBuf
   const uint4* cand_grow = ob.cand_grow + static_cast<size_t>(frame) * ob.pcap;
   const uint32_t* biglist = ob.biglist + static_cast<size_t>(frame) * ob.pcap;
   const int* hdr = ob.hdr + static_cast<size_t>(frame) * 48;
-  const int ncand = hdr[3], nbig = hdr[kHdrBig];
+  const int ncand = hdr[3], nbig = hdr[kHdrBig], nhuge = hdr[kHdrHuge];
   const int ntasks = nbig + ((ncand + 63) >> 6);
   const int slot = lane >> 2, dir = lane & 3;
   const int delta = dir == 0 ? -nh : (dir == 1 ? nh : (dir == 2 ? -1 : 1));
   const uint32_t opp = static_cast<uint32_t>(dir ^ 1);
+  // ---- huge grows first, the whole workgroup on one at a time
+  if (nhuge > 0) {
+    extern __shared__ __align__(16) unsigned char dsm[];
+    uint8_t* st = dsm;
+    uint32_t* ring = reinterpret_cast<uint32_t*>(dsm + (static_cast<size_t>(C) + 15u) / 16u * 16u);
+    uint32_t* bmap = ring + kHugeRing;
+    int* ctl = reinterpret_cast<int*>(bmap + kHugeHash);  // 0 task, 8.. per-wave winner counts
+    constexpr uint32_t kRingMask = kHugeRing - 1u;
+    const uint32_t notme = ~(1u << opp) & 0xFu;
+    for (;;) {
+      if (tid == 0) ctl[0] = atomicAdd(ob.task + 2 * frame + 1, 1);
+      for (int i = tid; i < kHugeHash; i += kOrderWaves * 64) bmap[i] = 0xFFFFFFFFu;
+      __syncthreads();
+      const int t = ctl[0];
+      if (t >= nhuge) break;
+      const uint4 cg = cand_grow[biglist[ob.pcap - 1 - t]];
+      const uint32_t g1 = cg.x + 1u;
+      const int gs = static_cast<int>(cg.y);
+      const uint32_t seed = cg.w & kCellMask;
+      for (int c = tid; c < C; c += kOrderWaves * 64) {
+        const uint32_t q = cellq[c];
+        st[c] = static_cast<uint8_t>((((q >> 4) == g1 && static_cast<uint32_t>(c) != seed) ? 1u : 0u) | ((q & 0xFu) << 2));
+      }
+      if (tid == 0) {
+        queue[gs] = seed;
+        ring[static_cast<uint32_t>(gs) & kRingMask] = seed;
+      }
+      __syncthreads();
+      int H = gs, T = gs + 1;
+      while (H < T) {
+        const int ns = (T - H) < 16 * kOrderWaves ? (T - H) : 16 * kOrderWaves;
+        const int gsl = wid * 16 + slot;  // slot of this lane's queue entry within the batch
+        const bool active = gsl < ns;
+        // (the frontier of a BFS over a grid is far narrower than the ring; should it ever not be, the batch comes from the
+        // queue in global memory, written through below)
+        const bool from_ring = (T - H) <= kHugeRing - 16 * kOrderWaves;
+        const int qi = H + (active ? gsl : 0);
+        const int u = from_ring ? static_cast<int>(ring[static_cast<uint32_t>(qi) & kRingMask])
+                                : static_cast<int>(__hip_atomic_load(queue + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        uint32_t myh = 0xFFFFFFFFu;
+        if (active && dir == 0) {  // the batch's cells into the map: cell << 8 | slot
+          uint32_t h = (static_cast<uint32_t>(u) * 2654435761u) >> 22;
+          const uint32_t key = (static_cast<uint32_t>(u) << 8) | static_cast<uint32_t>(gsl);
+          while (atomicCAS(&bmap[h], 0xFFFFFFFFu, key) != 0xFFFFFFFFu) h = (h + 1u) & (kHugeHash - 1u);
+          myh = h;
+        }
+        __syncthreads();
+        const int vraw = u + delta;
+        const bool inrange = active && vraw >= 0 && vraw < C;
+        const int v = vraw < 0 ? 0 : (vraw >= C ? C - 1 : vraw);
+        const uint32_t fv = st[v];
+        const uint32_t inb = (fv >> 2) & 0xFu;  // in-edge bits of v
+        bool win = inrange && (fv & 1u) != 0u && ((inb >> opp) & 1u) != 0u;
+        if (win) {
+          // u loses to any OTHER in-neighbour of v that sits earlier in this batch
+          const uint32_t others = inb & notme;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (win && ((others >> e) & 1u)) {
+              const int w = v + (e == 0 ? -nh : (e == 1 ? nh : (e == 2 ? -1 : 1)));
+              uint32_t h = (static_cast<uint32_t>(w) * 2654435761u) >> 22;
+              for (;;) {
+                const uint32_t k = bmap[h];
+                if (k == 0xFFFFFFFFu) break;
+                if ((k >> 8) == static_cast<uint32_t>(w)) {
+                  if (static_cast<int>(k & 0xFFu) < gsl) win = false;
+                  break;
+                }
+                h = (h + 1u) & (kHugeHash - 1u);
+              }
+            }
+        }
+        const unsigned long long mask = __ballot(win);
+        if (lane == 0) ctl[8 + wid] = static_cast<int>(__popcll(mask));
+        __syncthreads();
+        int off = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < kOrderWaves; ++w) {
+          const int cw = ctl[8 + w];
+          off += w < wid ? cw : 0;
+          tot += cw;
+        }
+        if (win) {
+          const int pos = T + off + static_cast<int>(__popcll(mask & lt_mask));
+          if (from_ring) queue[pos] = static_cast<uint32_t>(v);
+          else __hip_atomic_store(queue + pos, static_cast<uint32_t>(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ring[static_cast<uint32_t>(pos) & kRingMask] = static_cast<uint32_t>(v);
+          st[v] = static_cast<uint8_t>(fv & ~1u);
+        }
+        if (myh != 0xFFFFFFFFu) bmap[myh] = 0xFFFFFFFFu;
+        T += tot;
+        H += ns;
+        if (!from_ring) __threadfence();
+        __syncthreads();
+      }
+    }
+  }
   for (;;) {
     int t = 0;
-    if (lane == 0) t = atomicAdd(ob.task + frame, 1);
+    if (lane == 0) t = atomicAdd(ob.task + 2 * frame, 1);
     t = __builtin_amdgcn_readfirstlane(t);
     if (t >= ntasks) break;
     if (t < nbig) {
