@@ -105,7 +105,7 @@ struct dpx_handle_s {
            *d_histg = nullptr, *d_cgrow = nullptr, *d_cellq = nullptr, *d_worklist = nullptr, *d_biglist = nullptr, *d_ccursor = nullptr;
   int* d_order_task = nullptr;
   unsigned long long* d_hbest = nullptr;      // [B][T]
-  uint4* d_lists = nullptr;                   // [B][C] seed lists, one entry per (core, bin) pair
+  uint4* d_lists = nullptr;                   // [B][C][2] seed lists, one 32-byte entry per (core, bin) pair
   // staging for the host-pointer API (lazy)
   void* d_in = nullptr;
   size_t d_in_bytes = 0;
@@ -541,10 +541,13 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
       if (h->d_dbg) hipLaunchKernelGGL(dpx::k_regsim<true>, dim3(batch), dim3(64), h->lds3_sim, s, prm, sb);
       else hipLaunchKernelGGL(dpx::k_regsim<false>, dim3(batch), dim3(64), h->lds3_sim, s, prm, sb);
       hipLaunchKernelGGL(dpx::k_cellgrow, cell_grid, dim3(256), 0, s, prm, core_bufs(h));
+      const int per_frame_huge = std::max(1, std::min(4, 256 / std::max(1, batch)));
       if (h->d_dbg) {
-        hipLaunchKernelGGL(dpx::k_order<true>, dim3(per_frame, batch), dim3(dpx::kOrderWaves * 64), h->lds3_order, s, prm, ob);
+        hipLaunchKernelGGL((dpx::k_order<true, true>), dim3(per_frame_huge, batch), dim3(dpx::kOrderWaves * 64), h->lds3_order, s, prm, ob);
+        hipLaunchKernelGGL((dpx::k_order<true, false>), dim3(per_frame, batch), dim3(dpx::kOrderWaves * 64), 0, s, prm, ob);
       } else {
-        hipLaunchKernelGGL(dpx::k_order<false>, dim3(per_frame, batch), dim3(dpx::kOrderWaves * 64), h->lds3_order, s, prm, ob);
+        hipLaunchKernelGGL((dpx::k_order<false, true>), dim3(per_frame_huge, batch), dim3(dpx::kOrderWaves * 64), h->lds3_order, s, prm, ob);
+        hipLaunchKernelGGL((dpx::k_order<false, false>), dim3(per_frame, batch), dim3(dpx::kOrderWaves * 64), 0, s, prm, ob);
       }
       if (h->d_dbg) hipLaunchKernelGGL((dpx::k_regions2<0, true, 3>), dim3(batch), dim3(dpx::kTailRT), h->lds2_p3, s, prm, rb, rx);
       else hipLaunchKernelGGL((dpx::k_regions2<0, false, 3>), dim3(batch), dim3(dpx::kTailRT), h->lds2_p3, s, prm, rb, rx);
@@ -1063,7 +1066,7 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
     const size_t T = static_cast<size_t>(h->core_T);
     A(dev_alloc(&h->d_core, B * (17 * C + 2 * T + static_cast<size_t>(nb) + 8)));  // (+8: cursors [4], order task counters [2])
     A(dev_alloc(&h->d_hbest, B * T));
-    A(dev_alloc(&h->d_lists, B * C));
+    A(dev_alloc(&h->d_lists, B * C * 2));
     if (rc == DPX_OK) {
       uint32_t* q = h->d_core;
       auto take = [&](uint32_t*& dst, size_t n) { dst = q; q += B * n; };
@@ -1110,8 +1113,8 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
     }
   }
   if (rc == DPX_OK && h->cores && h->lds3_order + 8192 > 48 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_order<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds3_order)) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_order<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds3_order)) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_order<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds3_order)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_order<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds3_order)) != hipSuccess)
       rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
   }
   if (rc == DPX_OK && h->cores && h->lds3_sim > 48 * 1024) {
@@ -1459,7 +1462,7 @@ int64_t dpx_debug_read_cores(dpx_handle h, int32_t which, int32_t frame, void* o
     case 2: src = h->d_npairs + f * C; bytes = C * 4; break;
     case 3: src = h->d_pstart + f * C; bytes = C * 4; break;
     case 4: src = h->d_corepairs + f * C; bytes = C * 4; break;
-    case 5: src = h->d_lists + f * C; bytes = C * 16; break;
+    case 5: src = h->d_lists + f * C * 2; bytes = C * 32; break;
     case 6: src = h->d_bin_off + f * (nb + 1); bytes = (nb + 1) * 4; break;
     case 7: src = h->d_histg + f * nb; bytes = nb * 4; break;
     case 8: src = h->d_ccursor + f * 4; bytes = 16; break;

@@ -318,8 +318,9 @@ __global__ __launch_bounds__(256) void k_pair_scatter(Params prm, CoreBufs cb) {
   }
 }
 
-// sorted keys (dpx_binsort.h) -> lists[B][C]: the seed lists, one entry per pair — {leader cell | one-way-out << 31, core ID,
-// pairs of the core, cells of the core} — and bin_off[B][nb + 1] as k_sort_lists writes them
+// sorted keys (dpx_binsort.h) -> lists[B][C][2]: the seed lists, one 32-byte entry per pair — {leader cell | one-way-out
+// << 31, core ID, pairs of the core, cells of the core} and the first four (bin | count << 13) pairs of the core, so that the
+// sequence launch needs no further load for a core of up to four bins — and bin_off[B][nb + 1] as k_sort_lists writes them
 __global__ __launch_bounds__(256) void k_sort_lists_pairs(Params prm, const unsigned long long* __restrict__ keys, int Cpad, CoreBufs cb,
                                                           uint4* __restrict__ lists, uint32_t* __restrict__ bin_off) {
   const long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
@@ -339,13 +340,21 @@ __global__ __launch_bounds__(256) void k_sort_lists_pairs(Params prm, const unsi
     const size_t fo = static_cast<size_t>(frame) * prm.C;
     const uint32_t cell = static_cast<uint32_t>(key & kCellMask);
     const uint32_t r = cb.parent[fo + cell];
-    lists[fo + pos] = make_uint4(cell | (cb.noe[fo + r] ? kCoreOut : 0u), cb.pstart[fo + r], cb.npairs[fo + r], cb.csize[fo + r]);
+    const uint32_t ps = cb.pstart[fo + r], np = cb.npairs[fo + r];
+    uint4 pr = make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t* cp = cb.corepairs + fo + ps;
+    pr.x = cp[0];
+    if (np > 1) pr.y = cp[1];
+    if (np > 2) pr.z = cp[2];
+    if (np > 3) pr.w = cp[3];
+    lists[2 * (fo + pos)] = make_uint4(cell | (cb.noe[fo + r] ? kCoreOut : 0u), ps, np, cb.csize[fo + r]);
+    lists[2 * (fo + pos) + 1] = pr;
   }
 }
 
 // ---- the sequence of grows --------------------------------------------------------------------------------------------
 struct SimBufs {
-  const uint4* lists;                 // [B][C]  seed lists (k_sort_lists_pairs)
+  const uint4* lists;                 // [B][C][2]  seed lists (k_sort_lists_pairs)
   const uint32_t* bin_off;            // [B][nb + 1]
   const uint32_t* histg;              // [B][nb]
   const uint32_t* corepairs;          // [B][C]
@@ -373,7 +382,7 @@ constexpr int kHugeMin = 1024;
 constexpr int kWin = 4;  // seed-list entries per bin kept in LDS
 
 struct S3Layout {
-  uint32_t hist, cursor, lo, hi, bclaim, nzlist, evb, rrec, rsrc, win, cbits, end;
+  uint32_t hist, cursor, lo, hi, bclaim, nzlist, evb, rrec, rsrc, idata, win, cbits, end;
 };
 __host__ __device__ inline S3Layout s3_layout(int nb, int C) {
   S3Layout L{};
@@ -388,7 +397,8 @@ __host__ __device__ inline S3Layout s3_layout(int nb, int C) {
   L.evb = o; o += 128;
   L.rrec = o; o += 64 * 8;
   L.rsrc = o; o += 64;
-  L.win = o; o += 16u * kWin * static_cast<uint32_t>(nb);
+  L.idata = o; o += 64 * 4;
+  L.win = o; o += 32u * kWin * static_cast<uint32_t>(nb);
   L.cbits = o; o += 4u * static_cast<uint32_t>((C + 31) / 32 + 1);
   L.end = (o + 15u) & ~15u;
   return L;
@@ -402,6 +412,8 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
 #endif
   const unsigned long long t_start = DBG ? static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) : 0ull;
   unsigned long long n_rounds = 0, n_wide = 0, n_irreg = 0, n_refill = 0, n_multi = 0, n_skip = 0, t_setup = 0;
+  unsigned long long a_ev = 0, a_seed = 0, a_items = 0, a_walk = 0, a_commit = 0, a_wide = 0, ts0 = 0, ts1 = 0;
+#define S3_STAMP(acc) do { if (DBG) { ts1 = static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()); acc += ts1 - ts0; ts0 = ts1; } } while (0)
   const int frame = blockIdx.x, lane = threadIdx.x;
   const int C = prm.C;
   const int nb = prm.hist_B * prm.hist_B;
@@ -418,11 +430,12 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
   uint16_t* evb = reinterpret_cast<uint16_t*>(smem + lay.evb);
   uint2* rrec = reinterpret_cast<uint2*>(smem + lay.rrec);
   uint8_t* rsrc = smem + lay.rsrc;
-  uint4* win = reinterpret_cast<uint4*>(smem + lay.win);
+  uint4* win = reinterpret_cast<uint4*>(smem + lay.win);          // [bin][kWin][2]
+  uint32_t* idata = reinterpret_cast<uint32_t*>(smem + lay.idata);  // a round's items: bin | count << 13
   uint32_t* cbits = reinterpret_cast<uint32_t*>(smem + lay.cbits);  // bit (core ID): the core is unassigned
 
   const size_t fo = static_cast<size_t>(frame) * C;
-  const uint4* lists = sb.lists + fo;
+  const uint4* lists = sb.lists + 2 * fo;
   const uint32_t* corepairs = sb.corepairs + fo;
   uint32_t* cgrow = sb.cgrow + fo;
   uint4* cand_grow = sb.cand_grow + static_cast<size_t>(frame) * sb.pcap;
@@ -438,7 +451,15 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
       const int hv = static_cast<int>(hg[b]);
       hist[b] = hv;
       lo[b] = static_cast<int>(s0);
-      hi[b] = static_cast<int>(s0);
+      const int n0 = static_cast<int>(s1 - s0) < kWin ? static_cast<int>(s1 - s0) : kWin;
+      hi[b] = static_cast<int>(s0) + n0;  // every window starts filled (the loads of all bins are in flight together)
+#pragma unroll
+      for (int k = 0; k < kWin; ++k)
+        if (k < n0) {
+          const int sl = (b * kWin + ((static_cast<int>(s0) + k) & (kWin - 1))) * 2;
+          win[sl] = lists[2 * (static_cast<int>(s0) + k)];
+          win[sl + 1] = lists[2 * (static_cast<int>(s0) + k) + 1];
+        }
       cursor[b] = static_cast<int>(s1);
       bclaim[b] = 0xFFFFFFFFu;
     }
@@ -470,8 +491,14 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
   for (int q = 0; q < 4; ++q) mybin[q] = (lane + 64 * q < nnz) ? static_cast<int>(nzlist[lane + 64 * q]) : -1;
   const int nsets = (nnz + 63) >> 6;
   int cont_b = -1, cont_level = 0;
+  // a window that an event empties is refilled ahead of time: the loads are issued at the event's commit, their data is
+  // written to the window at the top of the next round — a cold list entry is ~3 000 cycles away, a round of other work
+  int pf_bin = -1, pf_pos = 0, pf_n = 0;
+  uint4 pf[2 * kWin];
+#pragma unroll
+  for (int k = 0; k < 2 * kWin; ++k) pf[k] = make_uint4(0u, 0u, 0u, 0u);
   for (int guard = 0; remaining > 0 && guard <= C; ++guard) {
-    if (DBG) ++n_rounds;
+    if (DBG) { ++n_rounds; ts0 = static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()); }
     // ---- the events of this round: the bins at the histogram's maximum, ascending = lane order (dpx_regions2.h, "sweep
     // rounds": a bin whose turn comes with its count still at the level has lost no cell since the sweep began)
     int b = -1, bv = 0, nev = 0;
@@ -567,6 +594,22 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
       cont_level = bv;
     }
     const int bs = b >= 0 ? b : 0;
+    if (__ballot(pf_bin >= 0)) {  // last round's prefetches
+      if (pf_bin >= 0) {
+#pragma unroll
+        for (int k = 0; k < kWin; ++k)
+          if (k < pf_n) {
+            const int sl = (pf_bin * kWin + ((pf_pos + k) & (kWin - 1))) * 2;
+            win[sl] = pf[2 * k];
+            win[sl + 1] = pf[2 * k + 1];
+          }
+        hi[pf_bin] = pf_pos + pf_n;
+        pf_bin = -1;
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+    S3_STAMP(a_ev);
     // ---- seeds: the first live entry of each bin's list (one entry per (core, bin) pair, sorted by the leader's mse, then
     // cell id: plane_extractor.cpp:309-316).  The next few entries of every list sit in an LDS window; a list is read from
     // global memory only when its window runs empty.
@@ -577,28 +620,37 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
     bool need = part, broken = false;
     for (;;) {
       if (need) {
+        // the window's (up to) four entries and their cores' bits in two LDS round trips; the first live one is the seed
+        uint4 x[kWin];
+        bool ok[kWin];
 #pragma unroll
-        for (int k = 0; k < kWin; ++k)
-          if (need && pos < whi) {
-            const uint4 x = win[bs * kWin + (pos & (kWin - 1))];
-            if (alive(x.y)) {
-              e = x;
-              need = false;
-            } else {
-              ++pos;
-            }
+        for (int k = 0; k < kWin; ++k) x[k] = win[(bs * kWin + ((pos + k) & (kWin - 1))) * 2];
+#pragma unroll
+        for (int k = 0; k < kWin; ++k) ok[k] = pos + k < whi && alive(x[k].y);
+        int adv = whi - pos;  // (no live entry: the window is used up)
+#pragma unroll
+        for (int k = kWin - 1; k >= 0; --k)
+          if (ok[k]) {
+            e = x[k];
+            adv = k;
           }
+        need = !(ok[0] || ok[1] || ok[2] || ok[3]);
+        pos += adv;
       }
       if (!__ballot(need)) break;
       if (DBG) ++n_refill;
-      if (need) {  // (pos == whi here: the window is used up)
+      if (need) {  // (pos == whi here)
         if (pos >= lend) {  // cannot happen (a bin's count is the number of its live cells, every one behind a live leader)
           broken = true;
           need = false;
         } else {
 #pragma unroll
           for (int k = 0; k < kWin; ++k)
-            if (pos + k < lend) win[bs * kWin + ((pos + k) & (kWin - 1))] = lists[pos + k];
+            if (pos + k < lend) {
+              const int sl = (bs * kWin + ((pos + k) & (kWin - 1))) * 2;
+              win[sl] = lists[2 * (pos + k)];
+              win[sl + 1] = lists[2 * (pos + k) + 1];
+            }
           whi = pos + kWin < lend ? pos + kWin : lend;
         }
       }
@@ -606,6 +658,7 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
       __builtin_amdgcn_wave_barrier();
     }
     if (__ballot(broken)) break;
+    S3_STAMP(a_seed);
     const uint32_t cell = e.x & kCellMask;
     const bool cout_ = (e.x & kCoreOut) != 0u;
     const uint32_t cid = e.y;
@@ -633,6 +686,13 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
       const int off = incl_items - cnt;
       const int nitems = static_cast<int>(wave_max_u32(cnt > 0 ? static_cast<uint32_t>(incl_items) : 0u));
       rrec[lane] = make_uint2(cid, static_cast<uint32_t>(off));
+      if (cnt > 0) {  // the core's first four pairs travel with its list entry
+        const uint4 pr = win[(bs * kWin + (pos & (kWin - 1))) * 2 + 1];
+        idata[off] = pr.x;
+        idata[off + 1] = pr.y;
+        if (cnt > 2) idata[off + 2] = pr.z;
+        if (cnt > 3) idata[off + 3] = pr.w;
+      }
 #pragma unroll
       for (int i = 0; i < kItemMax; ++i)
         if (i < cnt) rsrc[off + i] = static_cast<uint8_t>(lane);
@@ -642,7 +702,8 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
       if (it_ok) {
         it_src = static_cast<int>(rsrc[lane]);
         const uint2 r = rrec[it_src];
-        const uint32_t pr = corepairs[r.x + static_cast<uint32_t>(lane) - r.y];
+        const int j = lane - static_cast<int>(r.y);
+        const uint32_t pr = j < 4 ? idata[lane] : corepairs[r.x + static_cast<uint32_t>(j)];
         it_bin = static_cast<int>(pr & kPairBinMask);
         it_cnt = static_cast<int>(pr >> kPairBinBits);
         atomicMin(&bclaim[it_bin], static_cast<uint32_t>(it_src));
@@ -654,6 +715,7 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
       __builtin_amdgcn_wave_barrier();
       if (it_ok) bclaim[it_bin] = 0xFFFFFFFFu;  // clean for the next round
     }
+    S3_STAMP(a_items);
     const bool flag = part && (!complete || lowb < static_cast<uint32_t>(lane));
     unsigned long long fl = __ballot(flag), skipped = 0ull;
     int stop = 64;
@@ -675,6 +737,7 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
       stop_wide = true;
       break;
     }
+    S3_STAMP(a_walk);
     // ---- commit the lanes that fire before the stop
     const unsigned long long cm = (stop >= 64 ? partmask : (partmask & ((1ull << stop) - 1ull))) & ~skipped;
     const bool cmt = ((cm >> lane) & 1ull) != 0ull;
@@ -682,6 +745,18 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
       const bool used = cmt || (stop_wide && lane == stop);
       lo[bs] = used ? pos + 1 : pos;
       hi[bs] = whi;
+      const int left = whi - (used ? pos + 1 : pos);  // entries the window still holds
+      if (left <= 1 && whi < lend) {  // (nearly) empty: fetch its next entries into the free slots
+        pf_bin = bs;
+        pf_pos = whi;
+        pf_n = lend - whi < kWin - left ? lend - whi : kWin - left;
+#pragma unroll
+        for (int k = 0; k < kWin; ++k)
+          if (k < pf_n) {
+            pf[2 * k] = lists[2 * (whi + k)];
+            pf[2 * k + 1] = lists[2 * (whi + k) + 1];
+          }
+      }
     }
     if (cm) {
       const int grank = static_cast<int>(__popcll(cm & lt_mask));
@@ -721,6 +796,7 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    S3_STAMP(a_commit);
     if (!stop_wide) continue;
     // ---- the stopping event fires alone: the pairs of its core(s) leave the histogram, 64 per step
     if (DBG) ++n_wide;
@@ -791,6 +867,7 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
     remaining -= gsize;
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    S3_STAMP(a_wide);
   }
   // the header the tail launch starts from (k_regions2 PHASE 3 reads hdr[0..3], its segment counter hdr[40] must be 0)
   int* ho = sb.hdr_out + static_cast<size_t>(frame) * 48;
@@ -810,10 +887,12 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
     d[1] = static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - t_start;
     d[11] = n_rounds; d[13] = static_cast<unsigned long long>(ngrow); d[14] = static_cast<unsigned long long>(ncand);
     d[15] = static_cast<unsigned long long>(tail); d[19] = n_refill; d[21] = n_wide; d[22] = n_skip; d[23] = n_irreg; d[28] = n_multi;
+    d[3] = a_ev; d[4] = a_seed; d[5] = a_items; d[6] = a_walk; d[7] = a_commit; d[8] = a_wide;
     d[29] = static_cast<unsigned long long>(sb.cursor[4 * frame]); d[30] = static_cast<unsigned long long>(nbig) | (static_cast<unsigned long long>(nhuge) << 32);
   }
 }
 
+#undef S3_STAMP
 // ---- per cell: the grow that took it (candidates only: other grows leave no trace) and its in-edge bits ------------------
 __global__ __launch_bounds__(256) void k_cellgrow(Params prm, CoreBufs cb) {
   const int frame = blockIdx.y;
@@ -856,7 +935,8 @@ constexpr int kHugeRingBits = 12, kHugeRing = 1 << kHugeRingBits;
 constexpr int kHugeHash = 1024;  // slots of the batch map (a batch holds up to 16 * kOrderWaves cells)
 __host__ __device__ inline size_t order_lds_bytes(int C) { return (static_cast<size_t>(C) + 15u) / 16u * 16u + 4u * kHugeRing + 4u * kHugeHash + 64u; }
 
-template <bool DBG>
+// HUGE = the launch that orders the huge grows (dynamic LDS: order_lds_bytes); the other launch takes the waves' tasks
+template <bool DBG, bool HUGE>
 __global__ __launch_bounds__(kOrderWaves * 64) void k_order(Params prm, OrderBufs ob) {
   const unsigned long long t_start = DBG ? static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) : 0ull;
   const int frame = blockIdx.y;
@@ -878,8 +958,9 @@ __global__ __launch_bounds__(kOrderWaves * 64) void k_order(Params prm, OrderBuf
   const int slot = lane >> 2, dir = lane & 3;
   const int delta = dir == 0 ? -nh : (dir == 1 ? nh : (dir == 2 ? -1 : 1));
   const uint32_t opp = static_cast<uint32_t>(dir ^ 1);
-  // ---- huge grows first, the whole workgroup on one at a time
-  if (nhuge > 0) {
+  // ---- huge grows, the whole workgroup on one at a time
+  if constexpr (HUGE) {
+    if (nhuge == 0) return;
     extern __shared__ __align__(16) unsigned char dsm[];
     uint8_t* st = dsm;
     uint32_t* ring = reinterpret_cast<uint32_t*>(dsm + (static_cast<size_t>(C) + 15u) / 16u * 16u);
@@ -974,6 +1055,7 @@ __global__ __launch_bounds__(kOrderWaves * 64) void k_order(Params prm, OrderBuf
         __syncthreads();
       }
     }
+    return;
   }
   for (;;) {
     int t = 0;
