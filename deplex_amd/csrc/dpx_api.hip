@@ -102,7 +102,7 @@ struct dpx_handle_s {
   uint32_t* d_core = nullptr;                 // one allocation for the uint32 arrays below
   uint32_t *d_parent = nullptr, *d_csize = nullptr, *d_npairs = nullptr, *d_pstart = nullptr, *d_pfill = nullptr, *d_noe = nullptr,
            *d_oestart = nullptr, *d_oefill = nullptr, *d_hkey = nullptr, *d_hcnt = nullptr, *d_corepairs = nullptr, *d_oedges = nullptr,
-           *d_histg = nullptr, *d_cgrow = nullptr, *d_cellq = nullptr, *d_worklist = nullptr, *d_biglist = nullptr, *d_ccursor = nullptr;
+           *d_histg = nullptr, *d_pbcnt = nullptr, *d_cgrow = nullptr, *d_cellq = nullptr, *d_worklist = nullptr, *d_biglist = nullptr, *d_ccursor = nullptr;
   int* d_order_task = nullptr;
   unsigned long long* d_hbest = nullptr;      // [B][T]
   uint4* d_lists = nullptr;                   // [B][C][2] seed lists, one 32-byte entry per (core, bin) pair
@@ -365,6 +365,7 @@ dpx::CoreBufs core_bufs(dpx_handle h) {
   cb.meta = h->d_meta; cb.mse_c = h->d_mse_c; cb.parent = h->d_parent; cb.csize = h->d_csize; cb.npairs = h->d_npairs; cb.pstart = h->d_pstart;
   cb.pfill = h->d_pfill; cb.noe = h->d_noe; cb.oestart = h->d_oestart; cb.oefill = h->d_oefill; cb.hkey = h->d_hkey; cb.hcnt = h->d_hcnt;
   cb.hbest = h->d_hbest; cb.corepairs = h->d_corepairs; cb.oedges = h->d_oedges; cb.keys = h->d_sort_keys; cb.histg = h->d_histg;
+  cb.pbcnt = h->d_pbcnt; cb.bin_off = h->d_bin_off; cb.lists = h->d_lists;
   cb.cgrow = h->d_cgrow; cb.cursor = h->d_ccursor; cb.cellq = h->d_cellq; cb.order_task = h->d_order_task;
   cb.T = h->core_T; cb.logT = h->core_logT; cb.Cpad = h->Cpad;
   return cb;
@@ -375,8 +376,7 @@ void launch_binsort(dpx_handle h, const dpx::Params& prm, hipStream_t s) {
   const int Cpad = h->Cpad, B = prm.batch;
   const long long slots = static_cast<long long>(B) * Cpad;
   const unsigned g256 = static_cast<unsigned>((slots + 255) / 256);
-  if (!h->cores)  // (the core path's keys, one per (core, bin) pair, come from k_pair_scatter)
-    hipLaunchKernelGGL(dpx::k_sort_build, dim3(g256), dim3(256), 0, s, prm, h->d_meta, h->d_mse_c, h->d_sort_keys, Cpad);
+  hipLaunchKernelGGL(dpx::k_sort_build, dim3(g256), dim3(256), 0, s, prm, h->d_meta, h->d_mse_c, h->d_sort_keys, Cpad);
   const int tile = Cpad < dpx::kSortTile ? Cpad : dpx::kSortTile;
   const unsigned tiles = static_cast<unsigned>(slots / tile);
   const size_t lds = static_cast<size_t>(tile) * 8;
@@ -386,11 +386,7 @@ void launch_binsort(dpx_handle h, const dpx::Params& prm, hipStream_t s) {
       hipLaunchKernelGGL(dpx::k_sort_global, dim3(static_cast<unsigned>((slots / 2 + 255) / 256)), dim3(256), 0, s, h->d_sort_keys, Cpad, B, j, k);
     hipLaunchKernelGGL(dpx::k_sort_tile, dim3(tiles), dim3(dpx::kSortThreads), lds, s, h->d_sort_keys, Cpad, tile, k);
   }
-  if (h->cores) {
-    hipLaunchKernelGGL(dpx::k_sort_lists_pairs, dim3(g256), dim3(256), 0, s, prm, h->d_sort_keys, Cpad, core_bufs(h), h->d_lists, h->d_bin_off);
-  } else {
-    hipLaunchKernelGGL(dpx::k_sort_lists, dim3(g256), dim3(256), 0, s, prm, h->d_sort_keys, Cpad, h->d_order, h->d_bin_off);
-  }
+  hipLaunchKernelGGL(dpx::k_sort_lists, dim3(g256), dim3(256), 0, s, prm, h->d_sort_keys, Cpad, h->d_order, h->d_bin_off);
 }
 
 int fill_sub(dpx_handle h, SubBatch& sb, const void* d_in, int32_t* d_labels, bool depth, float fx, float fy, float cx, float cy) {
@@ -501,9 +497,11 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
     hipLaunchKernelGGL(dpx::k_core_flatten, cell_grid, dim3(256), 0, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_pair_count, g_tab, dim3(256), 0, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_core_alloc, cell_grid, dim3(256), 0, s, prm, cb);
+    hipLaunchKernelGGL(dpx::k_bin_scan, dim3(static_cast<unsigned>(batch)), dim3(64), 0, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_pair_scatter, g_sc, dim3(256), 0, s, prm, cb);
+    hipLaunchKernelGGL(dpx::k_bin_sort, dim3(static_cast<unsigned>(nbins), static_cast<unsigned>(batch)), dim3(dpx::kBinSortT), 0, s, prm, cb);
   }
-  if (total > 0 && (h->regions_tier == 1 || h->regions_tier == 0) && !skip_r) launch_binsort(h, prm, s);
+  if (total > 0 && (h->regions_tier == 1 || h->regions_tier == 0) && !h->cores && !skip_r) launch_binsort(h, prm, s);
   if (prof) DPX_HIP(hipEventRecord(ev[3], s));
   dpx::RegionBufs rb{};
   rb.cells = h->d_cells; rb.meta = h->d_meta; rb.order = h->d_order; rb.grow_start = h->d_grow_start;
@@ -1064,7 +1062,7 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
   }
   if (h->cores) {
     const size_t T = static_cast<size_t>(h->core_T);
-    A(dev_alloc(&h->d_core, B * (17 * C + 2 * T + static_cast<size_t>(nb) + 8)));  // (+8: cursors [4], order task counters [2])
+    A(dev_alloc(&h->d_core, B * (17 * C + 2 * T + 2 * static_cast<size_t>(nb) + 8)));  // (+8: cursors [4], order task counters [2])
     A(dev_alloc(&h->d_hbest, B * T));
     A(dev_alloc(&h->d_lists, B * C * 2));
     if (rc == DPX_OK) {
@@ -1072,7 +1070,7 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
       auto take = [&](uint32_t*& dst, size_t n) { dst = q; q += B * n; };
       take(h->d_parent, C); take(h->d_csize, C); take(h->d_npairs, C); take(h->d_pstart, C); take(h->d_pfill, C); take(h->d_noe, C);
       take(h->d_oestart, C); take(h->d_oefill, C); take(h->d_corepairs, C); take(h->d_cgrow, C); take(h->d_cellq, C); take(h->d_worklist, C);
-      take(h->d_biglist, C); take(h->d_oedges, 4 * C); take(h->d_hkey, T); take(h->d_hcnt, T); take(h->d_histg, static_cast<size_t>(nb));
+      take(h->d_biglist, C); take(h->d_oedges, 4 * C); take(h->d_hkey, T); take(h->d_hcnt, T); take(h->d_histg, static_cast<size_t>(nb)); take(h->d_pbcnt, static_cast<size_t>(nb));
       take(h->d_ccursor, 4);
       h->d_order_task = reinterpret_cast<int*>(q);
     }

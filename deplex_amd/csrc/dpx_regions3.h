@@ -59,6 +59,9 @@ struct CoreBufs {
   uint32_t* oedges;       // [B][4C]  one-way edges grouped by source core: root of the target's core
   unsigned long long* keys;  // [B][Cpad] sort keys of the seed lists (dpx_binsort.h), one per pair
   uint32_t* histg;        // [B][nb]  cells per histogram bin
+  uint32_t* pbcnt;        // [B][nb]  pairs per bin, then the scatter cursor of the bin's segment
+  uint32_t* bin_off;      // [B][nb + 1] first slot of every bin's segment in keys / lists
+  uint4* lists;           // [B][C][2] the seed lists (k_bin_sort)
   uint32_t* cgrow;        // [B][C]   indexed by core ID: grow index + 1 (k_regsim)
   uint32_t* cursor;       // [B][4]   allocation cursors of corepairs / oedges, planar cells of the frame
   uint32_t* cellq;        // [B][C]   k_cellgrow: (grow + 1) << 4 | in-edge bits
@@ -162,9 +165,11 @@ __global__ __launch_bounds__(256) void k_core_init(Params prm, CoreBufs cb) {
     cc_store(cb.hcnt + to, 0u);
     cc_store64(cb.hbest + to, ~0ull);
   }
-  if (i < cb.Cpad) cb.keys[static_cast<size_t>(frame) * cb.Cpad + i] = ~0ull;
   const int nb = prm.hist_B * prm.hist_B;
-  if (i < nb) cc_store(cb.histg + static_cast<size_t>(frame) * nb + i, 0u);
+  if (i < nb) {
+    cc_store(cb.histg + static_cast<size_t>(frame) * nb + i, 0u);
+    cc_store(cb.pbcnt + static_cast<size_t>(frame) * nb + i, 0u);
+  }
   if (i == 0) {
     cc_store(cb.cursor + 4 * frame, 0u);
     cc_store(cb.cursor + 4 * frame + 1, 0u);
@@ -271,6 +276,7 @@ __global__ __launch_bounds__(256) void k_pair_count(Params prm, CoreBufs cb) {
   const uint32_t K = cb.hkey[static_cast<size_t>(frame) * cb.T + t];
   if (K == kPairEmpty) return;
   atomicAdd(cb.npairs + static_cast<size_t>(frame) * prm.C + (K >> kPairBinBits), 1u);
+  atomicAdd(cb.pbcnt + static_cast<size_t>(frame) * (prm.hist_B * prm.hist_B) + (K & kPairBinMask), 1u);
 }
 
 // grid (ceil(C / 256), B): room for every core's pairs and one-way edges
@@ -298,8 +304,11 @@ __global__ __launch_bounds__(256) void k_pair_scatter(Params prm, CoreBufs cb) {
       const uint32_t cnt = cb.hcnt[to];
       const uint32_t j = cb.pstart[fo + root] + atomicAdd(cb.pfill + fo + root, 1u);
       cb.corepairs[fo + j] = bin | (cnt << kPairBinBits);
-      cb.keys[static_cast<size_t>(frame) * cb.Cpad + j] = (static_cast<unsigned long long>(bin) << kKeyBinShift) | cb.hbest[to];
-      atomicAdd(cb.histg + static_cast<size_t>(frame) * (prm.hist_B * prm.hist_B) + bin, cnt);
+      // counting sort by bin: the pair's key goes to the next free slot of its bin's segment (k_bin_sort orders the segment)
+      const size_t bo = static_cast<size_t>(frame) * (prm.hist_B * prm.hist_B);
+      const uint32_t at = cb.bin_off[bo + frame + bin] + atomicAdd(cb.pbcnt + bo + bin, 1u);
+      cb.keys[static_cast<size_t>(frame) * cb.Cpad + at] = cb.hbest[to];  // mse key << 19 | leader cell
+      atomicAdd(cb.histg + bo + bin, cnt);
     }
   }
   if (i < prm.C) {
@@ -318,26 +327,84 @@ __global__ __launch_bounds__(256) void k_pair_scatter(Params prm, CoreBufs cb) {
   }
 }
 
-// sorted keys (dpx_binsort.h) -> lists[B][C][2]: the seed lists, one 32-byte entry per pair — {leader cell | one-way-out
-// << 31, core ID, pairs of the core, cells of the core} and the first four (bin | count << 13) pairs of the core, so that the
-// sequence launch needs no further load for a core of up to four bins — and bin_off[B][nb + 1] as k_sort_lists writes them
-__global__ __launch_bounds__(256) void k_sort_lists_pairs(Params prm, const unsigned long long* __restrict__ keys, int Cpad, CoreBufs cb,
-                                                          uint4* __restrict__ lists, uint32_t* __restrict__ bin_off) {
-  const long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
-  const long long total = static_cast<long long>(prm.batch) * Cpad;
-  if (i >= total) return;
+// grid (B), 64 threads: pairs per bin -> first slot of every bin's segment (bin_off[nb] = pairs of the frame); the counts
+// become the scatter cursors
+__global__ __launch_bounds__(64) void k_bin_scan(Params prm, CoreBufs cb) {
+  const int frame = blockIdx.x, lane = threadIdx.x;
   const int nb = prm.hist_B * prm.hist_B;
-  const int frame = static_cast<int>(i / Cpad), pos = static_cast<int>(i - static_cast<long long>(frame) * Cpad);
-  const unsigned long long key = keys[i];
-  const unsigned long long prev = pos > 0 ? keys[i - 1] : 0ull;
-  const int b = key == ~0ull ? nb : static_cast<int>(key >> kKeyBinShift);
-  const int pb = pos == 0 ? -1 : (prev == ~0ull ? nb : static_cast<int>(prev >> kKeyBinShift));
-  uint32_t* bo = bin_off + static_cast<size_t>(frame) * (nb + 1);
-  for (int x = pb + 1; x <= b && x <= nb; ++x) bo[x] = static_cast<uint32_t>(pos);
-  if (pos == Cpad - 1 && b < nb)
-    for (int x = b + 1; x <= nb; ++x) bo[x] = static_cast<uint32_t>(Cpad);
-  if (key != ~0ull && pos < prm.C) {
-    const size_t fo = static_cast<size_t>(frame) * prm.C;
+  uint32_t* cnt = cb.pbcnt + static_cast<size_t>(frame) * nb;
+  uint32_t* bo = cb.bin_off + static_cast<size_t>(frame) * (nb + 1);
+  int carry = 0;
+  for (int base = 0; base < nb; base += 64) {
+    const int b = base + lane;
+    const int v = b < nb ? static_cast<int>(cnt[b]) : 0;
+    const int incl = wave_incl_scan_i32(v);
+    if (b < nb) {
+      bo[b] = static_cast<uint32_t>(carry + incl - v);
+      cc_store(cnt + b, 0u);
+    }
+    carry += __builtin_amdgcn_readlane(incl, 63);
+  }
+  if (lane == 0) bo[nb] = static_cast<uint32_t>(carry);
+}
+
+// grid (nb, B), kBinSortT threads: one bin's segment of pair keys (mse key << 19 | leader cell) sorted ascending — the
+// reference's "first minimum-MSE cell, lowest id among equals" (plane_extractor.cpp:309-316) is then the first live entry
+// — and written out as the seed list: one 32-byte entry per pair, {leader cell | one-way-out << 31, core ID, pairs of the
+// core, cells of the core} and the first four (bin | count << 13) pairs of the core, so that the sequence launch needs no
+// further load for a core of up to four bins.  Segments of up to kBinSortMax keys are sorted in LDS (all-ascending bitonic
+// network on exactly n keys, as in dpx_regions2.h's preparation), longer ones in place in global memory by the same
+// workgroup.
+constexpr int kBinSortT = 256, kBinSortMax = 4096;
+__global__ __launch_bounds__(kBinSortT) void k_bin_sort(Params prm, CoreBufs cb) {
+  const int frame = blockIdx.y, bin = blockIdx.x, tid = threadIdx.x;
+  const int nb = prm.hist_B * prm.hist_B;
+  const uint32_t* bo = cb.bin_off + static_cast<size_t>(frame) * (nb + 1);
+  const int s0 = static_cast<int>(bo[bin]), n = static_cast<int>(bo[bin + 1]) - s0;
+  if (n <= 0) return;
+  __shared__ unsigned long long sk[kBinSortMax];
+  unsigned long long* g = cb.keys + static_cast<size_t>(frame) * cb.Cpad + s0;
+  const bool in_lds = n <= kBinSortMax;
+  if (in_lds) {
+    for (int i = tid; i < n; i += kBinSortT) sk[i] = g[i];
+    __syncthreads();
+  }
+  if (n > 1) {
+    auto ld = [&](int i) { return in_lds ? sk[i] : __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto st = [&](int i, unsigned long long v) {
+      if (in_lds) sk[i] = v;
+      else __hip_atomic_store(g + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto cex = [&](int lo, int hi) {
+      if (hi < n) {
+        const unsigned long long a = ld(lo), b = ld(hi);
+        if (a > b) {
+          st(lo, b);
+          st(hi, a);
+        }
+      }
+    };
+    auto sync = [&]() {
+      if (!in_lds) __threadfence();
+      __syncthreads();
+    };
+    const int half = (n + 1) >> 1;
+    for (int k = 2; (k >> 1) < n; k <<= 1) {
+      const int hk = k >> 1;
+      for (int pi = tid; pi < ((n + k - 1) / k) * hk; pi += kBinSortT) {  // mirror step: i against the block's k-1-i
+        const int blk = pi / hk, off = pi - blk * hk;
+        cex(blk * k + off, blk * k + (k - 1 - off));
+      }
+      sync();
+      for (int j = k >> 2; j >= 1; j >>= 1) {  // half-cleaners: i against i + j
+        for (int pi = tid; pi < half + j; pi += kBinSortT) cex(((pi & ~(j - 1)) << 1) | (pi & (j - 1)), (((pi & ~(j - 1)) << 1) | (pi & (j - 1))) | j);
+        sync();
+      }
+    }
+  }
+  const size_t fo = static_cast<size_t>(frame) * prm.C;
+  for (int i = tid; i < n; i += kBinSortT) {
+    const unsigned long long key = in_lds ? sk[i] : __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t cell = static_cast<uint32_t>(key & kCellMask);
     const uint32_t r = cb.parent[fo + cell];
     const uint32_t ps = cb.pstart[fo + r], np = cb.npairs[fo + r];
@@ -347,8 +414,8 @@ __global__ __launch_bounds__(256) void k_sort_lists_pairs(Params prm, const unsi
     if (np > 1) pr.y = cp[1];
     if (np > 2) pr.z = cp[2];
     if (np > 3) pr.w = cp[3];
-    lists[2 * (fo + pos)] = make_uint4(cell | (cb.noe[fo + r] ? kCoreOut : 0u), ps, np, cb.csize[fo + r]);
-    lists[2 * (fo + pos) + 1] = pr;
+    cb.lists[2 * (fo + s0 + i)] = make_uint4(cell | (cb.noe[fo + r] ? kCoreOut : 0u), ps, np, cb.csize[fo + r]);
+    cb.lists[2 * (fo + s0 + i) + 1] = pr;
   }
 }
 

@@ -26,7 +26,10 @@ cases.append(("ragged 333x517", synth.synth_batch(2, 333, 517, seed0=3), synth.i
 cases.append(("synth1280 s0..", synth.synth_batch(3, 960, 1280, seed0=0), synth.intrinsics_for(960, 1280), O.default_config()))
 cases.append(("quilt1280", np.stack([synth.quilt_depth(960, 1280, seed=s) for s in range(2)]), synth.intrinsics_for(960, 1280), O.default_config()))
 cases.append(("quilt1280 jitter", np.stack([synth.quilt_depth(960, 1280, seed=3, jitter=2.0)]), synth.intrinsics_for(960, 1280), O.default_config()))
+cases.append(("quilt1280 3x3 bins", np.stack([synth.quilt_depth(960, 1280, seed=5)]), synth.intrinsics_for(960, 1280), O.default_config(histogram_bins_per_coord=3)))
+cases.append(("synth640 1 bin", synth.synth_batch(2, 480, 640, seed0=2), synth.intrinsics_for(480, 640), O.default_config(histogram_bins_per_coord=1)))
 if not quick:
+    cases.append(("quilt4k 2x2 bins (segments beyond the LDS sort)", np.stack([synth.quilt_depth(2160, 3840, seed=2)]), synth.intrinsics_for(2160, 3840), O.default_config(histogram_bins_per_coord=2)))
     cases.append(("synth4k s0..3", synth.synth_batch(4, 2160, 3840, seed0=0), synth.intrinsics_for(2160, 3840), O.default_config()))
     cases.append(("quilt4k", np.stack([synth.quilt_depth(2160, 3840, seed=1)]), synth.intrinsics_for(2160, 3840), O.default_config()))
 fails = 0
