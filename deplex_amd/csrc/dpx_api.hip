@@ -101,10 +101,12 @@ struct dpx_handle_s {
   size_t lds3_order = 0;                      // dynamic LDS of the order launch (a huge grow's cells, ring, batch map)
   uint32_t* d_core = nullptr;                 // one allocation for the uint32 arrays below
   uint32_t *d_parent = nullptr, *d_csize = nullptr, *d_npairs = nullptr, *d_pstart = nullptr, *d_pfill = nullptr, *d_noe = nullptr,
-           *d_oestart = nullptr, *d_oefill = nullptr, *d_hkey = nullptr, *d_hcnt = nullptr, *d_corepairs = nullptr, *d_oedges = nullptr,
+           *d_oestart = nullptr, *d_oefill = nullptr, *d_hkey = nullptr, *d_hcnt = nullptr, *d_corepairs = nullptr,
            *d_histg = nullptr, *d_pbcnt = nullptr, *d_cgrow = nullptr, *d_cellq = nullptr, *d_worklist = nullptr, *d_biglist = nullptr, *d_ccursor = nullptr;
   int* d_order_task = nullptr;
   unsigned long long* d_hbest = nullptr;      // [B][T]
+  uint4* d_oedges = nullptr;                  // [B][4C] one-way edges with their target core's data
+  uint2* d_crec = nullptr;                    // [B][C] by core ID: first one-way edge, number of edges
   uint4* d_lists = nullptr;                   // [B][C][2] seed lists, one 32-byte entry per (core, bin) pair
   // staging for the host-pointer API (lazy)
   void* d_in = nullptr;
@@ -161,6 +163,8 @@ void free_all(dpx_handle h) {
   hipFree(h->d_gqueue);
   hipFree(h->d_core);
   hipFree(h->d_hbest);
+  hipFree(h->d_oedges);
+  hipFree(h->d_crec);
   hipFree(h->d_lists);
   hipFree(h->d_sort_keys);
   hipFree(h->d_bin_off);
@@ -364,7 +368,7 @@ dpx::CoreBufs core_bufs(dpx_handle h) {
   dpx::CoreBufs cb{};
   cb.meta = h->d_meta; cb.mse_c = h->d_mse_c; cb.parent = h->d_parent; cb.csize = h->d_csize; cb.npairs = h->d_npairs; cb.pstart = h->d_pstart;
   cb.pfill = h->d_pfill; cb.noe = h->d_noe; cb.oestart = h->d_oestart; cb.oefill = h->d_oefill; cb.hkey = h->d_hkey; cb.hcnt = h->d_hcnt;
-  cb.hbest = h->d_hbest; cb.corepairs = h->d_corepairs; cb.oedges = h->d_oedges; cb.keys = h->d_sort_keys; cb.histg = h->d_histg;
+  cb.hbest = h->d_hbest; cb.corepairs = h->d_corepairs; cb.oedges = h->d_oedges; cb.crec = h->d_crec; cb.keys = h->d_sort_keys; cb.histg = h->d_histg;
   cb.pbcnt = h->d_pbcnt; cb.bin_off = h->d_bin_off; cb.lists = h->d_lists;
   cb.cgrow = h->d_cgrow; cb.cursor = h->d_ccursor; cb.cellq = h->d_cellq; cb.order_task = h->d_order_task;
   cb.T = h->core_T; cb.logT = h->core_logT; cb.Cpad = h->Cpad;
@@ -491,14 +495,14 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
     const int n_init = std::max(std::max(prm.C, h->core_T), std::max(h->Cpad, nbins));
     const dim3 g_init(static_cast<unsigned>((n_init + 255) / 256), static_cast<unsigned>(batch));
     const dim3 g_tab(static_cast<unsigned>((h->core_T + 255) / 256), static_cast<unsigned>(batch));
-    const dim3 g_sc(static_cast<unsigned>((std::max(prm.C, h->core_T) + 255) / 256), static_cast<unsigned>(batch));
     hipLaunchKernelGGL(dpx::k_core_init, g_init, dim3(256), 0, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_core_link, cell_grid, dim3(256), 0, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_core_flatten, cell_grid, dim3(256), 0, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_pair_count, g_tab, dim3(256), 0, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_core_alloc, cell_grid, dim3(256), 0, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_bin_scan, dim3(static_cast<unsigned>(batch)), dim3(64), 0, s, prm, cb);
-    hipLaunchKernelGGL(dpx::k_pair_scatter, g_sc, dim3(256), 0, s, prm, cb);
+    hipLaunchKernelGGL(dpx::k_pair_scatter, g_tab, dim3(256), 0, s, prm, cb);
+    hipLaunchKernelGGL(dpx::k_edge_scatter, cell_grid, dim3(256), 0, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_bin_sort, dim3(static_cast<unsigned>(nbins), static_cast<unsigned>(batch)), dim3(dpx::kBinSortT), 0, s, prm, cb);
   }
   if (total > 0 && (h->regions_tier == 1 || h->regions_tier == 0) && !h->cores && !skip_r) launch_binsort(h, prm, s);
@@ -524,8 +528,7 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   } else if (h->cores) {
     if (total > 0) {
       dpx::SimBufs sb{};
-      sb.lists = h->d_lists; sb.bin_off = h->d_bin_off; sb.histg = h->d_histg; sb.corepairs = h->d_corepairs; sb.oedges = h->d_oedges;
-      sb.parent = h->d_parent; sb.csize = h->d_csize; sb.npairs = h->d_npairs; sb.pstart = h->d_pstart; sb.noe = h->d_noe; sb.oestart = h->d_oestart;
+      sb.lists = h->d_lists; sb.bin_off = h->d_bin_off; sb.histg = h->d_histg; sb.corepairs = h->d_corepairs; sb.oedges = h->d_oedges; sb.crec = h->d_crec;
       sb.cursor = h->d_ccursor; sb.cgrow = h->d_cgrow; sb.worklist = h->d_worklist;
       sb.cand_grow = reinterpret_cast<uint4*>(h->d_cand_grow); sb.biglist = h->d_biglist;
       sb.hdr_out = reinterpret_cast<int*>(h->d_lds_img); sb.pcap = h->pcap;
@@ -1062,15 +1065,17 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
   }
   if (h->cores) {
     const size_t T = static_cast<size_t>(h->core_T);
-    A(dev_alloc(&h->d_core, B * (17 * C + 2 * T + 2 * static_cast<size_t>(nb) + 8)));  // (+8: cursors [4], order task counters [2])
+    A(dev_alloc(&h->d_core, B * (15 * C + 2 * T + 2 * static_cast<size_t>(nb) + 8)));
+    A(dev_alloc(&h->d_oedges, B * 4 * C));
+    A(dev_alloc(&h->d_crec, B * C));  // (+8: cursors [4], order task counters [2])
     A(dev_alloc(&h->d_hbest, B * T));
     A(dev_alloc(&h->d_lists, B * C * 2));
     if (rc == DPX_OK) {
       uint32_t* q = h->d_core;
       auto take = [&](uint32_t*& dst, size_t n) { dst = q; q += B * n; };
       take(h->d_parent, C); take(h->d_csize, C); take(h->d_npairs, C); take(h->d_pstart, C); take(h->d_pfill, C); take(h->d_noe, C);
-      take(h->d_oestart, C); take(h->d_oefill, C); take(h->d_corepairs, C); take(h->d_cgrow, C); take(h->d_cellq, C); take(h->d_worklist, C);
-      take(h->d_biglist, C); take(h->d_oedges, 4 * C); take(h->d_hkey, T); take(h->d_hcnt, T); take(h->d_histg, static_cast<size_t>(nb)); take(h->d_pbcnt, static_cast<size_t>(nb));
+      take(h->d_oestart, C); take(h->d_oefill, C); take(h->d_corepairs, C); take(h->d_cgrow, C); take(h->d_cellq, C); take(h->d_worklist, 3 * C);
+      take(h->d_biglist, C); take(h->d_hkey, T); take(h->d_hcnt, T); take(h->d_histg, static_cast<size_t>(nb)); take(h->d_pbcnt, static_cast<size_t>(nb));
       take(h->d_ccursor, 4);
       h->d_order_task = reinterpret_cast<int*>(q);
     }

@@ -56,7 +56,9 @@ struct CoreBufs {
   uint32_t* hcnt;         // [B][T]   cells of the pair
   unsigned long long* hbest;  // [B][T] min(mse key << 19 | cell): the pair's leader
   uint32_t* corepairs;    // [B][C]   pairs grouped by core: bin | count << 13
-  uint32_t* oedges;       // [B][4C]  one-way edges grouped by source core: root of the target's core
+  uint4* oedges;          // [B][4C]  one-way edges grouped by source core: the TARGET core as {ID | one-way-out << 31,
+                          //          pairs, cells, first pair} (k_edge_scatter)
+  uint2* crec;            // [B][C]   by core ID: {first one-way edge, one-way edges}
   unsigned long long* keys;  // [B][Cpad] sort keys of the seed lists (dpx_binsort.h), one per pair
   uint32_t* histg;        // [B][nb]  cells per histogram bin
   uint32_t* pbcnt;        // [B][nb]  pairs per bin, then the scatter cursor of the bin's segment
@@ -286,12 +288,15 @@ __global__ __launch_bounds__(256) void k_core_alloc(Params prm, CoreBufs cb) {
   if (c >= prm.C) return;
   const size_t fo = static_cast<size_t>(frame) * prm.C;
   if (cb.csize[fo + c] == 0u) return;  // (only roots of planar cores have a size)
-  cb.pstart[fo + c] = atomicAdd(cb.cursor + 4 * frame, cb.npairs[fo + c]);
+  const uint32_t ps = atomicAdd(cb.cursor + 4 * frame, cb.npairs[fo + c]);
+  cb.pstart[fo + c] = ps;
   const uint32_t ne = cb.noe[fo + c];
-  if (ne) cb.oestart[fo + c] = atomicAdd(cb.cursor + 4 * frame + 1, ne);
+  const uint32_t es = ne ? atomicAdd(cb.cursor + 4 * frame + 1, ne) : 0u;
+  cb.oestart[fo + c] = es;
+  cb.crec[fo + ps] = make_uint2(es, ne);
 }
 
-// grid (ceil(max(T, C) / 256), B): pairs into their core's list + their sort key; one-way edges into their core's list
+// grid (ceil(T / 256), B): pairs into their core's list + their sort key into its bin's segment
 __global__ __launch_bounds__(256) void k_pair_scatter(Params prm, CoreBufs cb) {
   const int frame = blockIdx.y;
   const int i = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
@@ -311,20 +316,31 @@ __global__ __launch_bounds__(256) void k_pair_scatter(Params prm, CoreBufs cb) {
       atomicAdd(cb.histg + bo + bin, cnt);
     }
   }
-  if (i < prm.C) {
-    const uint32_t m = cb.meta[fo + i];
-    const uint32_t ow = (m & F_UNASSIGNED) ? (((m >> 2) & ~(m >> 8)) & 0xFu) : 0u;
-    if (ow) {
-      const uint32_t r = cb.parent[fo + i];
+}
+
+// grid (ceil(C / 256), B), after k_pair_scatter: every one-way edge that leaves its core goes to its source core's list as
+// the TARGET core's {ID | one-way-out << 31, pairs, cells, first pair}: a grow that follows the edge to a one-bin core
+// without further one-way edges — the usual case — needs nothing else
+__global__ __launch_bounds__(256) void k_edge_scatter(Params prm, CoreBufs cb) {
+  const int frame = blockIdx.y;
+  const int i = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= prm.C) return;
+  const size_t fo = static_cast<size_t>(frame) * prm.C;
+  const uint32_t m = cb.meta[fo + i];
+  const uint32_t ow = (m & F_UNASSIGNED) ? (((m >> 2) & ~(m >> 8)) & 0xFu) : 0u;
+  if (!ow) return;
+  const uint32_t r = cb.parent[fo + i];
 #pragma unroll
-      for (int dir = 0; dir < 4; ++dir)
-        if ((ow >> dir) & 1u) {
-          const int v = i + (dir == 0 ? -prm.nh : (dir == 1 ? prm.nh : (dir == 2 ? -1 : 1)));
-          const uint32_t rv = cb.parent[fo + v];
-          if (rv != r) cb.oedges[4 * fo + cb.oestart[fo + r] + atomicAdd(cb.oefill + fo + r, 1u)] = rv;
-        }
+  for (int dir = 0; dir < 4; ++dir)
+    if ((ow >> dir) & 1u) {
+      const int v = i + (dir == 0 ? -prm.nh : (dir == 1 ? prm.nh : (dir == 2 ? -1 : 1)));
+      const uint32_t rv = cb.parent[fo + v];
+      if (rv != r) {
+        const uint32_t ps = cb.pstart[fo + rv];
+        cb.oedges[4 * fo + cb.oestart[fo + r] + atomicAdd(cb.oefill + fo + r, 1u)] =
+            make_uint4(ps | (cb.noe[fo + rv] ? kCoreOut : 0u), cb.npairs[fo + rv], cb.csize[fo + rv], cb.corepairs[fo + ps]);
+      }
     }
-  }
 }
 
 // grid (B), 64 threads: pairs per bin -> first slot of every bin's segment (bin_off[nb] = pairs of the frame); the counts
@@ -352,7 +368,7 @@ __global__ __launch_bounds__(64) void k_bin_scan(Params prm, CoreBufs cb) {
 // reference's "first minimum-MSE cell, lowest id among equals" (plane_extractor.cpp:309-316) is then the first live entry
 // — and written out as the seed list: one 32-byte entry per pair, {leader cell | one-way-out << 31, core ID, pairs of the
 // core, cells of the core} and the first four (bin | count << 13) pairs of the core, so that the sequence launch needs no
-// further load for a core of up to four bins.  Segments of up to kBinSortMax keys are sorted in LDS (all-ascending bitonic
+// further load for a core of up to four bins (a core with one-way edges out: two pairs, first edge, number of edges).  Segments of up to kBinSortMax keys are sorted in LDS (all-ascending bitonic
 // network on exactly n keys, as in dpx_regions2.h's preparation), longer ones in place in global memory by the same
 // workgroup.
 constexpr int kBinSortT = 256, kBinSortMax = 4096;
@@ -414,7 +430,12 @@ __global__ __launch_bounds__(kBinSortT) void k_bin_sort(Params prm, CoreBufs cb)
     if (np > 1) pr.y = cp[1];
     if (np > 2) pr.z = cp[2];
     if (np > 3) pr.w = cp[3];
-    cb.lists[2 * (fo + s0 + i)] = make_uint4(cell | (cb.noe[fo + r] ? kCoreOut : 0u), ps, np, cb.csize[fo + r]);
+    const uint32_t ne = cb.noe[fo + r];
+    if (ne) {  // a core with one-way edges out: two pairs + where its edges are
+      pr.z = cb.oestart[fo + r];
+      pr.w = ne;
+    }
+    cb.lists[2 * (fo + s0 + i)] = make_uint4(cell | (ne ? kCoreOut : 0u), ps, np, cb.csize[fo + r]);
     cb.lists[2 * (fo + s0 + i) + 1] = pr;
   }
 }
@@ -425,16 +446,11 @@ struct SimBufs {
   const uint32_t* bin_off;            // [B][nb + 1]
   const uint32_t* histg;              // [B][nb]
   const uint32_t* corepairs;          // [B][C]
-  const uint32_t* oedges;             // [B][4C]
-  const uint32_t* parent;             // [B][C]
-  const uint32_t* csize;              // per root
-  const uint32_t* npairs;
-  const uint32_t* pstart;
-  const uint32_t* noe;
-  const uint32_t* oestart;
+  const uint4* oedges;                // [B][4C]
+  const uint2* crec;                  // [B][C]
   const uint32_t* cursor;             // [B][4]: pairs, one-way edges, planar cells of the frame
   uint32_t* cgrow;                    // [B][C]  by core ID: grow + 1
-  uint32_t* worklist;                 // [B][C]  cores of an irregular grow (roots)
+  uint32_t* worklist;                 // [B][3C] irregular grows: IDs of the cores taken [C], cores still to expand [C][2]
   uint4* cand_grow;                   // [B][pcap]  grow index, queue range [y, z), seed | kCandWide
   uint32_t* biglist;                  // [B][pcap]  candidate indices of the grows k_order gives a whole wave
   int* hdr_out;                       // [B][48] the header the tail launch starts from (k_regions2 hdr[] layout) + counts
@@ -447,9 +463,11 @@ constexpr uint32_t kCandWide = 0x80000000u;  // cand_grow.w: the grow is ordered
 constexpr int kHdrBig = 4, kHdrHuge = 5;
 constexpr int kHugeMin = 1024;
 constexpr int kWin = 4;  // seed-list entries per bin kept in LDS
+constexpr int kEdgePre = 4;  // one-way edges of an event's core fetched ahead of its turn
+constexpr int kWideLds = 64; // cores of an irregular grow listed in LDS (more: in global memory)
 
 struct S3Layout {
-  uint32_t hist, cursor, lo, hi, bclaim, nzlist, evb, rrec, rsrc, idata, win, cbits, end;
+  uint32_t hist, cursor, lo, hi, bclaim, nzlist, evb, rrec, rsrc, idata, edata, tk, td, win, cbits, end;
 };
 __host__ __device__ inline S3Layout s3_layout(int nb, int C) {
   S3Layout L{};
@@ -465,6 +483,9 @@ __host__ __device__ inline S3Layout s3_layout(int nb, int C) {
   L.rrec = o; o += 64 * 8;
   L.rsrc = o; o += 64;
   L.idata = o; o += 64 * 4;
+  L.edata = o; o += 64 * kEdgePre * 16;
+  L.tk = o; o += kWideLds * 4;
+  L.td = o; o += kWideLds * 8;
   L.win = o; o += 32u * kWin * static_cast<uint32_t>(nb);
   L.cbits = o; o += 4u * static_cast<uint32_t>((C + 31) / 32 + 1);
   L.end = (o + 15u) & ~15u;
@@ -499,6 +520,9 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
   uint8_t* rsrc = smem + lay.rsrc;
   uint4* win = reinterpret_cast<uint4*>(smem + lay.win);          // [bin][kWin][2]
   uint32_t* idata = reinterpret_cast<uint32_t*>(smem + lay.idata);  // a round's items: bin | count << 13
+  uint4* edata = reinterpret_cast<uint4*>(smem + lay.edata);        // [lane][kEdgePre] first one-way edges of the lane's core
+  uint32_t* tkl = reinterpret_cast<uint32_t*>(smem + lay.tk);       // an irregular grow's first cores: IDs taken,
+  uint2* tdl = reinterpret_cast<uint2*>(smem + lay.td);             // cores still to expand
   uint32_t* cbits = reinterpret_cast<uint32_t*>(smem + lay.cbits);  // bit (core ID): the core is unassigned
 
   const size_t fo = static_cast<size_t>(frame) * C;
@@ -728,6 +752,18 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
     S3_STAMP(a_seed);
     const uint32_t cell = e.x & kCellMask;
     const bool cout_ = (e.x & kCoreOut) != 0u;
+    // An event whose core has one-way edges out fires alone, later in this round; its first edges are fetched now, for all
+    // such lanes at once, and parked in LDS before the walk (the load's latency hides behind the claims)
+    uint4 epre[kEdgePre];
+#pragma unroll
+    for (int k = 0; k < kEdgePre; ++k) epre[k] = make_uint4(0u, 0u, 0u, 0u);
+    const unsigned long long outmask = __ballot(part && cout_);
+    if (part && cout_) {
+      const uint4 eb = win[(bs * kWin + (pos & (kWin - 1))) * 2 + 1];
+#pragma unroll
+      for (int k = 0; k < kEdgePre; ++k)
+        if (static_cast<uint32_t>(k) < eb.w) epre[k] = sb.oedges[4 * fo + eb.z + k];
+    }
     const uint32_t cid = e.y;
     const int np = part ? static_cast<int>(e.z) : 0;
     const int csz = part ? static_cast<int>(e.w) : 0;
@@ -783,8 +819,20 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
       if (it_ok) bclaim[it_bin] = 0xFFFFFFFFu;  // clean for the next round
     }
     S3_STAMP(a_items);
-    const bool flag = part && (!complete || lowb < static_cast<uint32_t>(lane));
-    unsigned long long fl = __ballot(flag), skipped = 0ull;
+    if (outmask) {
+      if (part && cout_) {
+#pragma unroll
+        for (int k = 0; k < kEdgePre; ++k) edata[lane * kEdgePre + k] = epre[k];
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // A round is walked in SEGMENTS: the lanes up to the first event that must fire alone are committed together, that event
+    // fires, the lanes behind it whose bin is still at the level go on (the others have lost a cell: skipped), and so on.
+    unsigned long long pending = partmask, skipped = 0ull, usedmask = 0ull;
+    for (;;) {
+    const bool flag = part && ((pending >> lane) & 1ull) != 0ull && (!complete || lowb < static_cast<uint32_t>(lane));
+    unsigned long long fl = __ballot(flag);
     int stop = 64;
     bool stop_wide = false;
     while (fl) {  // lanes in order; only the flagged ones need a look
@@ -806,25 +854,9 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
     }
     S3_STAMP(a_walk);
     // ---- commit the lanes that fire before the stop
-    const unsigned long long cm = (stop >= 64 ? partmask : (partmask & ((1ull << stop) - 1ull))) & ~skipped;
+    const unsigned long long cm = (stop >= 64 ? pending : (pending & ((1ull << stop) - 1ull))) & ~skipped;
     const bool cmt = ((cm >> lane) & 1ull) != 0ull;
-    if (part) {
-      const bool used = cmt || (stop_wide && lane == stop);
-      lo[bs] = used ? pos + 1 : pos;
-      hi[bs] = whi;
-      const int left = whi - (used ? pos + 1 : pos);  // entries the window still holds
-      if (left <= 1 && whi < lend) {  // (nearly) empty: fetch its next entries into the free slots
-        pf_bin = bs;
-        pf_pos = whi;
-        pf_n = lend - whi < kWin - left ? lend - whi : kWin - left;
-#pragma unroll
-        for (int k = 0; k < kWin; ++k)
-          if (k < pf_n) {
-            pf[2 * k] = lists[2 * (whi + k)];
-            pf[2 * k + 1] = lists[2 * (whi + k) + 1];
-          }
-      }
-    }
+    usedmask |= cm;
     if (cm) {
       const int grank = static_cast<int>(__popcll(cm & lt_mask));
       const int ncm = static_cast<int>(__popcll(cm));
@@ -864,61 +896,120 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     S3_STAMP(a_commit);
-    if (!stop_wide) continue;
-    // ---- the stopping event fires alone: the pairs of its core(s) leave the histogram, 64 per step
+    if (!stop_wide) break;
+    // ---- the stopping event fires alone: the pairs of its core(s) leave the histogram
     if (DBG) ++n_wide;
+    usedmask |= 1ull << stop;
     const uint32_t wcell = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cell), stop));
     const uint32_t wcid = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cid), stop));
     const int wnp = __builtin_amdgcn_readlane(np, stop);
     const int wsz = __builtin_amdgcn_readlane(csz, stop);
     const bool wout = ((__ballot(cout_) >> stop) & 1ull) != 0ull;
-    auto take_pairs = [&](uint32_t pst, int n) {
-      for (int i = lane; i < n; i += 64) {
+    uint4 wB = make_uint4(0u, 0u, 0u, 0u);  // the second half of its list entry
+    if (lane == stop) wB = win[(bs * kWin + (pos & (kWin - 1))) * 2 + 1];
+    wB.x = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wB.x), stop));
+    wB.y = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wB.y), stop));
+    wB.z = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wB.z), stop));
+    wB.w = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(wB.w), stop));
+    // pairs [from, n) of a core out of corepairs, 64 per step
+    auto take_pairs = [&](uint32_t pst, int from, int n) {
+      for (int i = from + lane; i < n; i += 64) {
         const uint32_t pr = corepairs[pst + static_cast<uint32_t>(i)];
         atomicSub(&hist[pr & kPairBinMask], static_cast<int>(pr >> kPairBinBits));
       }
     };
-    int gsize = wsz;
-    int nwl = 0;
     if (lane == 0) atomicAnd(&cbits[wcid >> 5], ~(1u << (wcid & 31u)));
-    take_pairs(wcid, wnp);
+    {
+      const int ninl = wout ? (wnp < 2 ? wnp : 2) : (wnp < 4 ? wnp : 4);  // pairs that came with the list entry
+      const uint32_t pr = lane == 0 ? wB.x : (lane == 1 ? wB.y : (lane == 2 ? wB.z : wB.w));
+      if (lane < ninl) atomicSub(&hist[pr & kPairBinMask], static_cast<int>(pr >> kPairBinBits));
+      take_pairs(wcid, ninl, wnp);
+    }
+    int gsize = wsz;
+    int ntaken = 1;
     if (wout) {
       if (DBG) ++n_irreg;
-      // the cores reachable from the seed's core over one-way edges among the cores still unassigned, in any order (the
-      // SET is what the sequence needs; k_order finds the activation order)
-      uint32_t* wl = sb.worklist + fo;
-      const uint32_t root0 = sb.parent[fo + wcell];
+      // The cores reachable from the seed's core over one-way edges among the cores still unassigned, in any order (the SET
+      // is what the sequence needs; k_order finds the activation order).  An edge carries its target core's ID, pair count,
+      // size and first pair, so a target of one bin without edges of its own is done on the spot; the others wait in `todo`.
+      uint32_t* taken = sb.worklist + 3 * fo;   // IDs of the grow's cores (for the marks k_cellgrow reads)
+      uint32_t* todo = taken + C;               // {ID | one-way-out << 31, pairs}
       if (lane == 0) {
-        hdr[8] = 1;
-        wl[0] = root0;
+        hdr[8] = 0;   // todo entries
+        hdr[9] = 1;   // cores taken
+        tkl[0] = wcid;
       }
-      wave_sync();
-      for (int wi = 0;; ++wi) {
-        nwl = *static_cast<volatile int*>(&hdr[8]);
-        if (wi >= nwl) break;
-        const uint32_t r = __hip_atomic_load(wl + wi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t ne = sb.noe[fo + r], es = sb.oestart[fo + r];
-        if (wi > 0) {  // (the seed's core is accounted for above)
-          gsize += static_cast<int>(sb.csize[fo + r]);
-          take_pairs(sb.pstart[fo + r], static_cast<int>(sb.npairs[fo + r]));
-        }
-        for (uint32_t i = lane; i < ne; i += 64) {
-          const uint32_t rv = sb.oedges[4 * fo + es + i];
-          const uint32_t id = sb.pstart[fo + rv];
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      int lsize = 0;
+      auto visit = [&](const uint4 ed) {
+        {
+          const uint32_t id = ed.x & ~kCoreOut;
           // a core is unassigned as long as its bit is set; whoever clears it has found the core
           const uint32_t bit = 1u << (id & 31u);
           const uint32_t old = atomicAnd(&cbits[id >> 5], ~bit);
-          if (old & bit) wl[atomicAdd(&hdr[8], 1)] = rv;
+          if (old & bit) {
+            lsize += static_cast<int>(ed.z);
+            const int tk = atomicAdd(&hdr[9], 1);
+            if (tk < kWideLds) tkl[tk] = id;
+            else taken[tk] = id;
+            if (ed.y == 1u) atomicSub(&hist[ed.w & kPairBinMask], static_cast<int>(ed.w >> kPairBinBits));
+            if (ed.y != 1u || (ed.x & kCoreOut)) {
+              const int at = atomicAdd(&hdr[8], 1);
+              if (at < kWideLds) {
+                tdl[at] = make_uint2(ed.x, ed.y);
+              } else {
+                todo[2 * at] = ed.x;
+                todo[2 * at + 1] = ed.y;
+              }
+            }
+          }
         }
-        wave_sync();
+      };
+      auto expand = [&](uint32_t es, uint32_t from, uint32_t ne) {
+        for (uint32_t i = from + lane; i < ne; i += 64) visit(sb.oedges[4 * fo + es + i]);
+      };
+      if (static_cast<uint32_t>(lane) < wB.w && lane < kEdgePre) visit(edata[stop * kEdgePre + lane]);  // (fetched ahead)
+      expand(wB.z, kEdgePre, wB.w);
+      // (lists beyond kWideLds entries are in global memory: their stores must be visible before they are read back)
+      auto list_sync = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (*static_cast<volatile int*>(&hdr[8]) > kWideLds || *static_cast<volatile int*>(&hdr[9]) > kWideLds) wave_sync();
+      };
+      list_sync();
+      for (int ti = 0;; ++ti) {
+        const int ntodo = *static_cast<volatile int*>(&hdr[8]);
+        if (ti >= ntodo) break;
+        uint32_t tx;
+        int tnp;
+        if (ti < kWideLds) {
+          const uint2 t2 = tdl[ti];
+          tx = t2.x;
+          tnp = static_cast<int>(t2.y);
+        } else {
+          tx = __hip_atomic_load(todo + 2 * ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          tnp = static_cast<int>(__hip_atomic_load(todo + 2 * ti + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        const uint32_t tid_ = tx & ~kCoreOut;
+        if (tnp != 1) take_pairs(tid_, 0, tnp);
+        if (tx & kCoreOut) {
+          const uint2 rec = sb.crec[fo + tid_];
+          expand(rec.x, 0u, rec.y);
+        }
+        list_sync();
       }
+      gsize += __builtin_amdgcn_readlane(wave_incl_scan_i32(lsize), 63);  // (DPP: the ds_bpermute butterfly of wave_sum costs ~800 cycles here)
+      ntaken = hdr[9];
     }
     const bool is_cand = !(static_cast<unsigned long long>(gsize) < static_cast<unsigned long long>(static_cast<long long>(prm.min_cells))) && ncand < sb.pcap;
     if (is_cand) {
       if (!wout) {
         if (lane == 0) cgrow[wcid] = static_cast<uint32_t>(ngrow + 1);
       } else {
-        for (int i = lane; i < nwl; i += 64) cgrow[sb.pstart[fo + sb.worklist[fo + i]]] = static_cast<uint32_t>(ngrow + 1);
+        const uint32_t* taken = sb.worklist + 3 * fo;
+        for (int i = lane; i < ntaken; i += 64)
+          cgrow[i < kWideLds ? tkl[i] : __hip_atomic_load(taken + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = static_cast<uint32_t>(ngrow + 1);
       }
       if (lane == 0) {
         cand_grow[ncand] = make_uint4(static_cast<uint32_t>(ngrow), static_cast<uint32_t>(tail), static_cast<uint32_t>(tail + gsize), wcell | kCandWide);
@@ -934,7 +1025,36 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
     remaining -= gsize;
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    // the lanes behind it: a bin still at the level has lost no cell — its event stands as computed; the others are out
+    {
+      const bool still = part && lane > stop && ((pending >> lane) & 1ull) != 0ull && ((skipped >> lane) & 1ull) == 0ull && hist[bs] == bv;
+      const unsigned long long stillmask = __ballot(still);
+      const unsigned long long above = stop >= 63 ? 0ull : (~0ull << (stop + 1));
+      skipped |= partmask & above & ~stillmask;
+      pending = stillmask;
+    }
     S3_STAMP(a_wide);
+    if (!pending) break;
+    }  // (segments)
+    if (part) {  // list heads and windows of the round's bins
+      const bool used = ((usedmask >> lane) & 1ull) != 0ull;
+      lo[bs] = used ? pos + 1 : pos;
+      hi[bs] = whi;
+      const int left = whi - (used ? pos + 1 : pos);  // entries the window still holds
+      if (left <= 1 && whi < lend) {  // (nearly) empty: fetch its next entries into the free slots
+        pf_bin = bs;
+        pf_pos = whi;
+        pf_n = lend - whi < kWin - left ? lend - whi : kWin - left;
+#pragma unroll
+        for (int k = 0; k < kWin; ++k)
+          if (k < pf_n) {
+            pf[2 * k] = lists[2 * (whi + k)];
+            pf[2 * k + 1] = lists[2 * (whi + k) + 1];
+          }
+      }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
   }
   // the header the tail launch starts from (k_regions2 PHASE 3 reads hdr[0..3], its segment counter hdr[40] must be 0)
   int* ho = sb.hdr_out + static_cast<size_t>(frame) * 48;
