@@ -102,7 +102,7 @@ struct dpx_handle_s {
   uint32_t* d_core = nullptr;                 // one allocation for the uint32 arrays below
   uint32_t *d_parent = nullptr, *d_csize = nullptr, *d_npairs = nullptr, *d_pstart = nullptr, *d_pfill = nullptr, *d_noe = nullptr,
            *d_oestart = nullptr, *d_oefill = nullptr, *d_hkey = nullptr, *d_hcnt = nullptr, *d_corepairs = nullptr,
-           *d_histg = nullptr, *d_pbcnt = nullptr, *d_cgrow = nullptr, *d_cellq = nullptr, *d_worklist = nullptr, *d_biglist = nullptr, *d_ccursor = nullptr;
+           *d_histg = nullptr, *d_pbcnt = nullptr, *d_hslots = nullptr, *d_cgrow = nullptr, *d_cellq = nullptr, *d_worklist = nullptr, *d_biglist = nullptr, *d_ccursor = nullptr;
   int* d_order_task = nullptr;
   unsigned long long* d_hbest = nullptr;      // [B][T]
   uint4* d_oedges = nullptr;                  // [B][4C] one-way edges with their target core's data
@@ -368,7 +368,7 @@ dpx::CoreBufs core_bufs(dpx_handle h) {
   dpx::CoreBufs cb{};
   cb.meta = h->d_meta; cb.mse_c = h->d_mse_c; cb.parent = h->d_parent; cb.csize = h->d_csize; cb.npairs = h->d_npairs; cb.pstart = h->d_pstart;
   cb.pfill = h->d_pfill; cb.noe = h->d_noe; cb.oestart = h->d_oestart; cb.oefill = h->d_oefill; cb.hkey = h->d_hkey; cb.hcnt = h->d_hcnt;
-  cb.hbest = h->d_hbest; cb.corepairs = h->d_corepairs; cb.oedges = h->d_oedges; cb.crec = h->d_crec; cb.keys = h->d_sort_keys; cb.histg = h->d_histg;
+  cb.hbest = h->d_hbest; cb.hslots = h->d_hslots; cb.corepairs = h->d_corepairs; cb.oedges = h->d_oedges; cb.crec = h->d_crec; cb.keys = h->d_sort_keys; cb.histg = h->d_histg;
   cb.pbcnt = h->d_pbcnt; cb.bin_off = h->d_bin_off; cb.lists = h->d_lists;
   cb.cgrow = h->d_cgrow; cb.cursor = h->d_ccursor; cb.cellq = h->d_cellq; cb.order_task = h->d_order_task;
   cb.T = h->core_T; cb.logT = h->core_logT; cb.Cpad = h->Cpad;
@@ -492,9 +492,10 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   if (total > 0 && h->cores && !skip_r) {  // cores of the symmetric edges and their (core, bin) pairs (dpx_regions3.h), before the seed lists
     const dpx::CoreBufs cb = core_bufs(h);
     const int nbins = prm.hist_B * prm.hist_B;
-    const int n_init = std::max(std::max(prm.C, h->core_T), std::max(h->Cpad, nbins));
+    const int n_init = std::max(prm.C, nbins);
     const dim3 g_init(static_cast<unsigned>((n_init + 255) / 256), static_cast<unsigned>(batch));
-    const dim3 g_tab(static_cast<unsigned>((h->core_T + 255) / 256), static_cast<unsigned>(batch));
+    const dim3 g_tab = cell_grid;  // (the occupied slots of the pair table: at most one per cell)
+    const int sort_wgs = std::max(4, std::min(std::min(64, nbins), 2048 / std::max(1, batch)));
     hipLaunchKernelGGL(dpx::k_core_init, g_init, dim3(256), 0, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_core_link, cell_grid, dim3(256), 0, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_core_flatten, cell_grid, dim3(256), 0, s, prm, cb);
@@ -503,7 +504,7 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
     hipLaunchKernelGGL(dpx::k_bin_scan, dim3(static_cast<unsigned>(batch)), dim3(64), 0, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_pair_scatter, g_tab, dim3(256), 0, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_edge_scatter, cell_grid, dim3(256), 0, s, prm, cb);
-    hipLaunchKernelGGL(dpx::k_bin_sort, dim3(static_cast<unsigned>(nbins), static_cast<unsigned>(batch)), dim3(dpx::kBinSortT), 0, s, prm, cb);
+    hipLaunchKernelGGL(dpx::k_bin_sort, dim3(static_cast<unsigned>(std::min(sort_wgs, nbins)), static_cast<unsigned>(batch)), dim3(dpx::kBinSortT), 0, s, prm, cb);
   }
   if (total > 0 && (h->regions_tier == 1 || h->regions_tier == 0) && !h->cores && !skip_r) launch_binsort(h, prm, s);
   if (prof) DPX_HIP(hipEventRecord(ev[3], s));
@@ -542,7 +543,7 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
       if (h->d_dbg) hipLaunchKernelGGL(dpx::k_regsim<true>, dim3(batch), dim3(64), h->lds3_sim, s, prm, sb);
       else hipLaunchKernelGGL(dpx::k_regsim<false>, dim3(batch), dim3(64), h->lds3_sim, s, prm, sb);
       hipLaunchKernelGGL(dpx::k_cellgrow, cell_grid, dim3(256), 0, s, prm, core_bufs(h));
-      const int per_frame_huge = std::max(1, std::min(4, 256 / std::max(1, batch)));
+      const int per_frame_huge = std::max(1, std::min(4, 128 / std::max(1, batch)));
       if (h->d_dbg) {
         hipLaunchKernelGGL((dpx::k_order<true, true>), dim3(per_frame_huge, batch), dim3(dpx::kOrderWaves * 64), h->lds3_order, s, prm, ob);
         hipLaunchKernelGGL((dpx::k_order<true, false>), dim3(per_frame, batch), dim3(dpx::kOrderWaves * 64), 0, s, prm, ob);
@@ -1065,7 +1066,7 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
   }
   if (h->cores) {
     const size_t T = static_cast<size_t>(h->core_T);
-    A(dev_alloc(&h->d_core, B * (15 * C + 2 * T + 2 * static_cast<size_t>(nb) + 8)));
+    A(dev_alloc(&h->d_core, B * (16 * C + 2 * T + 2 * static_cast<size_t>(nb) + 8)));
     A(dev_alloc(&h->d_oedges, B * 4 * C));
     A(dev_alloc(&h->d_crec, B * C));  // (+8: cursors [4], order task counters [2])
     A(dev_alloc(&h->d_hbest, B * T));
@@ -1075,9 +1076,13 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
       auto take = [&](uint32_t*& dst, size_t n) { dst = q; q += B * n; };
       take(h->d_parent, C); take(h->d_csize, C); take(h->d_npairs, C); take(h->d_pstart, C); take(h->d_pfill, C); take(h->d_noe, C);
       take(h->d_oestart, C); take(h->d_oefill, C); take(h->d_corepairs, C); take(h->d_cgrow, C); take(h->d_cellq, C); take(h->d_worklist, 3 * C);
-      take(h->d_biglist, C); take(h->d_hkey, T); take(h->d_hcnt, T); take(h->d_histg, static_cast<size_t>(nb)); take(h->d_pbcnt, static_cast<size_t>(nb));
+      take(h->d_biglist, C); take(h->d_hslots, C); take(h->d_hkey, T); take(h->d_hcnt, T); take(h->d_histg, static_cast<size_t>(nb)); take(h->d_pbcnt, static_cast<size_t>(nb));
       take(h->d_ccursor, 4);
       h->d_order_task = reinterpret_cast<int*>(q);
+      // the pair table starts empty; every call leaves it empty again (k_pair_scatter)
+      if (hipMemset(h->d_hkey, 0xFF, B * T * 4) != hipSuccess || hipMemset(h->d_hcnt, 0, B * T * 4) != hipSuccess ||
+          hipMemset(h->d_hbest, 0xFF, B * T * 8) != hipSuccess)
+        rc = fail(DPX_ERR_HIP, "hipMemset failed");
     }
   }
   if (std::getenv("DPX_RESIDENCY")) {

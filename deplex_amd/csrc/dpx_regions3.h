@@ -52,7 +52,8 @@ struct CoreBufs {
   uint32_t* noe;          // [B][C]   at the root: one-way edges to other cores (duplicates included)
   uint32_t* oestart;      // [B][C]
   uint32_t* oefill;       // [B][C]
-  uint32_t* hkey;         // [B][T]   hash table of the pairs: root << 13 | bin
+  uint32_t* hkey;         // [B][T]   hash table of the pairs: root << 13 | bin (empty between calls: k_pair_scatter resets what it reads)
+  uint32_t* hslots;       // [B][C]   the occupied slots, in insertion order (cursor[3] of them)
   uint32_t* hcnt;         // [B][T]   cells of the pair
   unsigned long long* hbest;  // [B][T] min(mse key << 19 | cell): the pair's leader
   uint32_t* corepairs;    // [B][C]   pairs grouped by core: bin | count << 13
@@ -122,7 +123,7 @@ __device__ __forceinline__ void cc_union(uint32_t* p, uint32_t a, uint32_t b) {
   }
 }
 // slot of pair key K in the frame's table: found or inserted
-__device__ __forceinline__ uint32_t pair_slot(uint32_t* hkey, int logT, uint32_t K) {
+__device__ __forceinline__ uint32_t pair_slot(uint32_t* hkey, int logT, uint32_t K, bool* isnew) {
   const uint32_t mask = (1u << logT) - 1u;
   uint32_t h = (K * 2654435761u) >> (32 - logT);
   for (;;) {
@@ -130,13 +131,17 @@ __device__ __forceinline__ uint32_t pair_slot(uint32_t* hkey, int logT, uint32_t
     if (k == K) return h;
     if (k == kPairEmpty) {
       const uint32_t old = atomicCAS(hkey + h, kPairEmpty, K);
-      if (old == kPairEmpty || old == K) return h;
+      if (old == kPairEmpty) {  // a new pair (the caller lists it, so that the later launches walk the pairs, not the table)
+        *isnew = true;
+        return h;
+      }
+      if (old == K) return h;
     }
     h = (h + 1u) & mask;
   }
 }
 
-// grid (ceil(max(C, T, Cpad) / 256), B), 256 threads
+// grid (ceil(max(C, bins) / 256), B), 256 threads
 __global__ __launch_bounds__(256) void k_core_init(Params prm, CoreBufs cb) {
   const int frame = blockIdx.y;
   const int i = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
@@ -161,12 +166,6 @@ __global__ __launch_bounds__(256) void k_core_init(Params prm, CoreBufs cb) {
     cc_store(cb.oefill + fo + i, 0u);
     cb.cgrow[fo + i] = 0u;  // (written by one wave of one later launch, read by the launch after it: plain)
   }
-  if (i < cb.T) {
-    const size_t to = static_cast<size_t>(frame) * cb.T + i;
-    cc_store(cb.hkey + to, kPairEmpty);
-    cc_store(cb.hcnt + to, 0u);
-    cc_store64(cb.hbest + to, ~0ull);
-  }
   const int nb = prm.hist_B * prm.hist_B;
   if (i < nb) {
     cc_store(cb.histg + static_cast<size_t>(frame) * nb + i, 0u);
@@ -176,6 +175,7 @@ __global__ __launch_bounds__(256) void k_core_init(Params prm, CoreBufs cb) {
     cc_store(cb.cursor + 4 * frame, 0u);
     cc_store(cb.cursor + 4 * frame + 1, 0u);
     cc_store(cb.cursor + 4 * frame + 2, 0u);
+    cc_store(cb.cursor + 4 * frame + 3, 0u);
     __hip_atomic_store(cb.order_task + 2 * frame, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(cb.order_task + 2 * frame + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -250,6 +250,8 @@ __global__ __launch_bounds__(256) void k_core_flatten(Params prm, CoreBufs cb) {
                                      ? (static_cast<unsigned long long>(sort_mse_key(cb.mse_c[fo + c])) << kCellBits) | static_cast<unsigned long long>(c)
                                      : ~0ull;
   todo = __ballot(K != kPairEmpty);
+  bool mynew = false;
+  uint32_t newslot = 0u;
   while (todo) {
     const int l = static_cast<int>(__builtin_ctzll(todo));
     const uint32_t K0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(K), l));
@@ -257,7 +259,8 @@ __global__ __launch_bounds__(256) void k_core_flatten(Params prm, CoreBufs cb) {
     const unsigned long long same = __ballot(mine);
     uint32_t slot = 0u;
     if (lane == l) {
-      slot = pair_slot(hkey, cb.logT, K0);
+      slot = pair_slot(hkey, cb.logT, K0, &mynew);
+      newslot = slot;
       atomicAdd(cb.hcnt + static_cast<size_t>(frame) * cb.T + slot, static_cast<uint32_t>(__popcll(same)));
     }
     slot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(slot), l));
@@ -267,16 +270,23 @@ __global__ __launch_bounds__(256) void k_core_flatten(Params prm, CoreBufs cb) {
     }
     todo &= ~same;
   }
-  (void)lt_mask;
+  // the slots this wave has newly occupied go to the frame's slot list: one atomic per wave
+  const unsigned long long newmask = __ballot(mynew);
+  if (newmask) {
+    uint32_t base = 0u;
+    const int first = static_cast<int>(__builtin_ctzll(newmask));
+    if (lane == first) base = atomicAdd(cb.cursor + 4 * frame + 3, static_cast<uint32_t>(__popcll(newmask)));
+    base = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(base), first));
+    if (mynew) cb.hslots[fo + base + static_cast<uint32_t>(__popcll(newmask & lt_mask))] = newslot;
+  }
 }
 
-// grid (ceil(T / 256), B): every pair counts for its core
+// grid (ceil(C / 256), B) over the list of occupied slots: every pair counts for its core
 __global__ __launch_bounds__(256) void k_pair_count(Params prm, CoreBufs cb) {
   const int frame = blockIdx.y;
-  const int t = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
-  if (t >= cb.T) return;
-  const uint32_t K = cb.hkey[static_cast<size_t>(frame) * cb.T + t];
-  if (K == kPairEmpty) return;
+  const int li = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
+  if (li >= static_cast<int>(cb.cursor[4 * frame + 3])) return;
+  const uint32_t K = cb.hkey[static_cast<size_t>(frame) * cb.T + cb.hslots[static_cast<size_t>(frame) * prm.C + li]];
   atomicAdd(cb.npairs + static_cast<size_t>(frame) * prm.C + (K >> kPairBinBits), 1u);
   atomicAdd(cb.pbcnt + static_cast<size_t>(frame) * (prm.hist_B * prm.hist_B) + (K & kPairBinMask), 1u);
 }
@@ -296,15 +306,15 @@ __global__ __launch_bounds__(256) void k_core_alloc(Params prm, CoreBufs cb) {
   cb.crec[fo + ps] = make_uint2(es, ne);
 }
 
-// grid (ceil(T / 256), B): pairs into their core's list + their sort key into its bin's segment
+// grid (ceil(C / 256), B) over the list of occupied slots: pairs into their core's list + their sort key into its bin's segment
 __global__ __launch_bounds__(256) void k_pair_scatter(Params prm, CoreBufs cb) {
   const int frame = blockIdx.y;
   const int i = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
   const size_t fo = static_cast<size_t>(frame) * prm.C;
-  if (i < cb.T) {
-    const size_t to = static_cast<size_t>(frame) * cb.T + i;
+  if (i < static_cast<int>(cb.cursor[4 * frame + 3])) {
+    const size_t to = static_cast<size_t>(frame) * cb.T + cb.hslots[fo + i];
     const uint32_t K = cb.hkey[to];
-    if (K != kPairEmpty) {
+    {
       const uint32_t root = K >> kPairBinBits, bin = K & kPairBinMask;
       const uint32_t cnt = cb.hcnt[to];
       const uint32_t j = cb.pstart[fo + root] + atomicAdd(cb.pfill + fo + root, 1u);
@@ -314,6 +324,10 @@ __global__ __launch_bounds__(256) void k_pair_scatter(Params prm, CoreBufs cb) {
       const uint32_t at = cb.bin_off[bo + frame + bin] + atomicAdd(cb.pbcnt + bo + bin, 1u);
       cb.keys[static_cast<size_t>(frame) * cb.Cpad + at] = cb.hbest[to];  // mse key << 19 | leader cell
       atomicAdd(cb.histg + bo + bin, cnt);
+      // the slot is empty again for the next call (write-through: the next call's atomics must find these values in memory)
+      cc_store(cb.hkey + to, kPairEmpty);
+      cc_store(cb.hcnt + to, 0u);
+      cc_store64(cb.hbest + to, ~0ull);
     }
   }
 }
@@ -364,7 +378,7 @@ __global__ __launch_bounds__(64) void k_bin_scan(Params prm, CoreBufs cb) {
   if (lane == 0) bo[nb] = static_cast<uint32_t>(carry);
 }
 
-// grid (nb, B), kBinSortT threads: one bin's segment of pair keys (mse key << 19 | leader cell) sorted ascending — the
+// grid (G, B), kBinSortT threads, bins dealt round robin: one bin's segment of pair keys (mse key << 19 | leader cell) sorted ascending — the
 // reference's "first minimum-MSE cell, lowest id among equals" (plane_extractor.cpp:309-316) is then the first live entry
 // — and written out as the seed list: one 32-byte entry per pair, {leader cell | one-way-out << 31, core ID, pairs of the
 // core, cells of the core} and the first four (bin | count << 13) pairs of the core, so that the sequence launch needs no
@@ -373,12 +387,14 @@ __global__ __launch_bounds__(64) void k_bin_scan(Params prm, CoreBufs cb) {
 // workgroup.
 constexpr int kBinSortT = 256, kBinSortMax = 4096;
 __global__ __launch_bounds__(kBinSortT) void k_bin_sort(Params prm, CoreBufs cb) {
-  const int frame = blockIdx.y, bin = blockIdx.x, tid = threadIdx.x;
+  const int frame = blockIdx.y, tid = threadIdx.x;
   const int nb = prm.hist_B * prm.hist_B;
   const uint32_t* bo = cb.bin_off + static_cast<size_t>(frame) * (nb + 1);
-  const int s0 = static_cast<int>(bo[bin]), n = static_cast<int>(bo[bin + 1]) - s0;
-  if (n <= 0) return;
   __shared__ unsigned long long sk[kBinSortMax];
+  for (int bin = blockIdx.x; bin < nb; bin += gridDim.x) {  // (a few workgroups per frame: most bins are empty)
+  const int s0 = static_cast<int>(bo[bin]), n = static_cast<int>(bo[bin + 1]) - s0;
+  if (n <= 0) continue;
+  __syncthreads();  // (sk is reused)
   unsigned long long* g = cb.keys + static_cast<size_t>(frame) * cb.Cpad + s0;
   const bool in_lds = n <= kBinSortMax;
   if (in_lds) {
@@ -437,6 +453,7 @@ __global__ __launch_bounds__(kBinSortT) void k_bin_sort(Params prm, CoreBufs cb)
     }
     cb.lists[2 * (fo + s0 + i)] = make_uint4(cell | (ne ? kCoreOut : 0u), ps, np, cb.csize[fo + r]);
     cb.lists[2 * (fo + s0 + i) + 1] = pr;
+  }
   }
 }
 
