@@ -107,6 +107,7 @@ struct dpx_handle_s {
   unsigned long long* d_hbest = nullptr;      // [B][T]
   uint4* d_oedges = nullptr;                  // [B][4C] one-way edges with their target core's data
   uint2* d_crec = nullptr;                    // [B][C] by core ID: first one-way edge, number of edges
+  float* d_candfit = nullptr;                 // [B][pcap][12] fits of the candidate segments (k_seg_fit)
   uint4* d_lists = nullptr;                   // [B][C][2] seed lists, one 32-byte entry per (core, bin) pair
   // staging for the host-pointer API (lazy)
   void* d_in = nullptr;
@@ -165,6 +166,7 @@ void free_all(dpx_handle h) {
   hipFree(h->d_hbest);
   hipFree(h->d_oedges);
   hipFree(h->d_crec);
+  hipFree(h->d_candfit);
   hipFree(h->d_lists);
   hipFree(h->d_sort_keys);
   hipFree(h->d_bin_off);
@@ -525,6 +527,15 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   rx.g_qpos = h->d_gqpos;
   rx.frames_per_out = per_sub;
   for (int j = 0; j < dpx::kMaxGroup; ++j) rx.labels_out[j] = (fuse_labels && j < nsub) ? subs[j].d_labels : nullptr;
+  // diagnostic (DPX_SYNC_EACH=1): wait for every launch of the core path and name it on stderr — finds a launch that never ends
+  static const bool sync_each = std::getenv("DPX_SYNC_EACH") != nullptr;
+  auto CHK = [&](const char* name) {
+    if (sync_each) {
+      const hipError_t e1 = hipStreamSynchronize(s);
+      std::fprintf(stderr, "[dpx] %s: %s\n", name, hipGetErrorString(e1));
+      std::fflush(stderr);
+    }
+  };
   if (skip_r) {
   } else if (h->cores) {
     if (total > 0) {
@@ -542,7 +553,9 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
       if (h->d_dbg) (void)hipMemsetAsync(h->d_dbg + (static_cast<size_t>(h->max_batch)) * dpx::kDbgSlots, 0, static_cast<size_t>(batch) * dpx::kDbgSlots * 8, s);
       if (h->d_dbg) hipLaunchKernelGGL(dpx::k_regsim<true>, dim3(batch), dim3(64), h->lds3_sim, s, prm, sb);
       else hipLaunchKernelGGL(dpx::k_regsim<false>, dim3(batch), dim3(64), h->lds3_sim, s, prm, sb);
+      CHK("k_regsim");
       hipLaunchKernelGGL(dpx::k_cellgrow, cell_grid, dim3(256), 0, s, prm, core_bufs(h));
+      CHK("k_cellgrow");
       const int per_frame_huge = std::max(1, std::min(4, 128 / std::max(1, batch)));
       if (h->d_dbg) {
         hipLaunchKernelGGL((dpx::k_order<true, true>), dim3(per_frame_huge, batch), dim3(dpx::kOrderWaves * 64), h->lds3_order, s, prm, ob);
@@ -551,8 +564,21 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
         hipLaunchKernelGGL((dpx::k_order<false, true>), dim3(per_frame_huge, batch), dim3(dpx::kOrderWaves * 64), h->lds3_order, s, prm, ob);
         hipLaunchKernelGGL((dpx::k_order<false, false>), dim3(per_frame, batch), dim3(dpx::kOrderWaves * 64), 0, s, prm, ob);
       }
-      if (h->d_dbg) hipLaunchKernelGGL((dpx::k_regions2<0, true, 3>), dim3(batch), dim3(dpx::kTailRT), h->lds2_p3, s, prm, rb, rx);
-      else hipLaunchKernelGGL((dpx::k_regions2<0, false, 3>), dim3(batch), dim3(dpx::kTailRT), h->lds2_p3, s, prm, rb, rx);
+      CHK("k_order");
+      // segment sums and fits chip-wide, then the per-frame remainder (ids, labels_map_, adjacency, merge walk, labels)
+      dpx::TailBufs tb{};
+      tb.cells = h->d_cells; tb.queue = h->d_gqueue; tb.cand_grow = reinterpret_cast<const uint4*>(h->d_cand_grow); tb.biglist = h->d_biglist;
+      tb.hdr = reinterpret_cast<const int*>(h->d_lds_img); tb.cand = h->d_cand; tb.candfit = h->d_candfit; tb.task = h->d_order_task; tb.pcap = h->pcap;
+      rx.candfit = h->d_candfit;
+      hipLaunchKernelGGL((dpx::k_seg_accum<true>), dim3(per_frame_huge, batch), dim3(dpx::kAccWaves * 64), 0, s, prm, tb);
+      CHK("k_seg_accum<huge>");
+      hipLaunchKernelGGL((dpx::k_seg_accum<false>), dim3(per_frame, batch), dim3(dpx::kAccWaves * 64), 0, s, prm, tb);
+      CHK("k_seg_accum");
+      hipLaunchKernelGGL(dpx::k_seg_fit, dim3(static_cast<unsigned>((h->pcap + 255) / 256), static_cast<unsigned>(batch)), dim3(256), 0, s, prm, tb);
+      CHK("k_seg_fit");
+      if (h->d_dbg) hipLaunchKernelGGL((dpx::k_regions2<0, true, 5>), dim3(batch), dim3(dpx::kTail5RT), h->lds2_p3, s, prm, rb, rx);
+      else hipLaunchKernelGGL((dpx::k_regions2<0, false, 5>), dim3(batch), dim3(dpx::kTail5RT), h->lds2_p3, s, prm, rb, rx);
+      CHK("k_regions2<0, ., 5>");
     }
   } else if (h->regions_tier == 0 && h->tier0_split && !h->d_dbg) {
     hipLaunchKernelGGL((dpx::k_regions2<0, false, 1>), dim3(batch), dim3(dpx::kRT), h->lds2_p1, s, prm, rb, rx);
@@ -1067,6 +1093,7 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
   if (h->cores) {
     const size_t T = static_cast<size_t>(h->core_T);
     A(dev_alloc(&h->d_core, B * (16 * C + 2 * T + 2 * static_cast<size_t>(nb) + 8)));
+    A(dev_alloc(&h->d_candfit, B * static_cast<size_t>(h->pcap) * 12));
     A(dev_alloc(&h->d_oedges, B * 4 * C));
     A(dev_alloc(&h->d_crec, B * C));  // (+8: cursors [4], order task counters [2])
     A(dev_alloc(&h->d_hbest, B * T));
@@ -1147,7 +1174,7 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
       } else {
         fns[0] = reinterpret_cast<const void*>(dpx::k_regions2<0, false, 1>);
         fns[1] = reinterpret_cast<const void*>(dpx::k_regions2<0, false, 2>);
-        fns[2] = reinterpret_cast<const void*>(dpx::k_regions2<0, false, 3>);
+        fns[2] = h->cores ? reinterpret_cast<const void*>(dpx::k_regions2<0, false, 5>) : reinterpret_cast<const void*>(dpx::k_regions2<0, false, 3>);
       }
       const size_t need[3] = {h->lds2_p1, h->lds2_p2, h->lds2_p3};
       for (int i = 0; i < 3 && rc == DPX_OK; ++i)
@@ -1504,7 +1531,7 @@ int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_
     DPX_HIP(hipMemset(h->d_dbg, 0, static_cast<size_t>(h->max_batch) * 2 * dpx::kDbgSlots * sizeof(unsigned long long)));
     if (h->cores) {
       if (h->lds2_p3 > 48 * 1024)
-        DPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<0, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds2_p3)));
+        DPX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regions2<0, true, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds2_p3)));
     } else if (h->lds2_bytes > 48 * 1024 && h->regions_tier >= 0) {
       const void* fn = h->regions_tier == 2   ? reinterpret_cast<const void*>(dpx::k_regions2<2, true, 0>)
                        : h->regions_tier == 1 ? reinterpret_cast<const void*>(dpx::k_regions2<1, true, 0>)

@@ -95,6 +95,10 @@ constexpr int kTailRT = DPX_TAIL_RT;
 #endif
 constexpr int kPrepRT = DPX_PREP_RT;
 static_assert(kTailRT % 64 == 0 && kTailRT <= kRT && kTailRT >= 64, "tail workgroup: whole waves, at most the preparation's");
+// PHASE 5 = the tail of the core-based path (dpx_regions3.h): segment sums and fits come from chip-wide launches, what is
+// left per frame — ordered ids, labels_map_, adjacency, the merge walk, final labels — is cell- and plane-parallel work around
+// one sequential walk, so the workgroup is as wide as the register file allows
+constexpr int kTail5RT = 1024;
 // entries of the per-wave staging buffer of the accumulation phase: 32 where the buffer reuses dead image arrays
 // (tier 2), 64 where it lies behind the image anyway (large frames: fewer, longer chunks per segment)
 __host__ __device__ constexpr int stage_entries(int tier) { return tier == 2 ? 32 : 64; }
@@ -185,6 +189,7 @@ struct Regions2Extra {
   unsigned long long* res;  // diagnostic (DPX_RESIDENCY=1): [B][4] shader-clock lifetime of the frame's workgroup in launch 1, 2, 3
   int32_t* labels_out[kMaxGroup];   // non-null: the tail also expands the cell labels to the pixel label map (fused K6);
   int frames_per_out;       // frame f writes to labels_out[f / frames_per_out] (grouped submissions have one buffer each)
+  const float* candfit;     // PHASE 5: [B][pcap][12] the candidate segments' fits (dpx_regions3.h k_seg_fit): mean, normal, d, mse, score, ok
 };
 
 constexpr int kDbgSlots = 32;  // words per frame of the diagnostic instantiation's output
@@ -218,9 +223,9 @@ template <int TIER, bool DBG, int PHASE>
 // (the fused preparation + grow launch is held at the 72 vector registers its preparation part needs: 73 would be
 // allocated as 80, and the launch shares its CUs with the plane-fit waves of the other groups)
 // (second launch bound: 7 workgroups of kPrepRT = 256 threads per CU = 7 waves per SIMD = at most 72 registers)
-__global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE == 4 ? kPrepRT : kRT)), PHASE == 4 ? 7 : 1) void k_regions2(Params prm, RegionBufs rb, Regions2Extra rx) {
+__global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE == 4 ? kPrepRT : (PHASE == 5 ? kTail5RT : kRT))), PHASE == 4 ? 7 : 1) void k_regions2(Params prm, RegionBufs rb, Regions2Extra rx) {
   // (inside the kernel kRT / kRW are THIS launch's workgroup size: the tail may run with fewer waves)
-  constexpr int kRT = PHASE == 3 ? dpx::kTailRT : (PHASE == 4 ? dpx::kPrepRT : (PHASE == 2 ? 64 : dpx::kRT));
+  constexpr int kRT = PHASE == 3 ? dpx::kTailRT : (PHASE == 4 ? dpx::kPrepRT : (PHASE == 2 ? 64 : (PHASE == 5 ? dpx::kTail5RT : dpx::kRT)));
   constexpr int kRW = kRT / 64;
   constexpr bool FULL = TIER == 2;
   constexpr bool HASBIN = TIER >= 1;  // bin of every cell in LDS (tier 0 reads the cell-graph words in global memory)
@@ -231,6 +236,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
   // regions are not widened over a workgroup there — the form is for streams of mid-size frames, see the host side)
   static_assert(PHASE != 4 || (TIER == 2 && !DBG), "the fused preparation + grow launch exists for tier 2");
   WaveTrace trace_(PHASE == 1 ? TK_PREP : ((PHASE == 2 || PHASE == 4) ? TK_GROW : TK_TAIL));
+  static_assert(PHASE != 5 || TIER == 0, "the core path's tail keeps its queue and label map in global memory");
 #if DPX_REGIONS_PRIO
   __builtin_amdgcn_s_setprio(DPX_REGIONS_PRIO);  // latency-bound waves: win issue arbitration against co-resident streaming kernels
 #endif
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
   float4* lds_v = reinterpret_cast<float4*>(smem);
   float4* img = rx.lds_img + static_cast<size_t>(frame) * (rx.img_bytes >> 4);
   const int img_vec = rx.img_bytes >> 4;
-  if (PHASE == 2 || PHASE == 3) {
+  if (PHASE == 2 || PHASE == 3 || PHASE == 5) {
     // continue from the previous launch's LDS image: gfx950 LDS-DMA (global_load_lds_dwordx4: lane l of a wave delivers
     // bytes [16 l, 16 l + 16) of a 1 KB chunk straight into LDS, no staging registers).  All chunks of a wave are in
     // flight together and awaited once — the plain copy loop compiles to load, wait, store per KB, i.e. 32 serialized
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
         if (base + lane < v1)
           __builtin_amdgcn_global_load_lds((dpx_glb_ptr)(img + base + lane), (dpx_lds_ptr)(lds_v + base), 16, 0, 0);
     };
-    if (PHASE == 3 && !GST) {
+    if ((PHASE == 3 || PHASE == 5) && !GST) {
       dma(0, hdr_v);
       dma(q_v0, q_v1 < img_vec ? q_v1 : img_vec);
     } else {
@@ -1474,7 +1480,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
   idx_t* lab16 = order;
   for (int c = tid; c < C; c += kRT) lab16[c] = 0;
   // ---------------- P2: exact float accumulation of every candidate segment (wave per segment) ------------
-  {
+  if constexpr (PHASE != 5) {
     constexpr int kStage = stage_entries(TIER);
     float* st = stage + wid * kStage * 9;
     const float4* cf4 = reinterpret_cast<const float4*>(cells);
@@ -1553,8 +1559,16 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
       pp[0] = co[3]; pp[1] = co[4]; pp[2] = co[5]; pp[3] = co[6]; pp[4] = co[7]; pp[5] = co[8];
       npts = __float_as_int(co[9]);
       gi = __float_as_int(co[10]);
-      fit_plane(s, pp, npts, fit);
-      ok = fit.score > prm.min_score;
+      if constexpr (PHASE == 5) {
+        const float* cf = rx.candfit + (static_cast<size_t>(frame) * rb.pcap + ci) * 12;
+        fit.mean[0] = cf[0]; fit.mean[1] = cf[1]; fit.mean[2] = cf[2];
+        fit.normal[0] = cf[3]; fit.normal[1] = cf[4]; fit.normal[2] = cf[5];
+        fit.d = cf[6]; fit.mse = cf[7]; fit.score = cf[8];
+        ok = __float_as_int(cf[9]) != 0;
+      } else {
+        fit_plane(s, pp, npts, fit);
+        ok = fit.score > prm.min_score;
+      }
     }
     const unsigned long long mask = __ballot(ok);
     if (lane == 0) hdr[16 + wid] = __popcll(mask);
@@ -1997,7 +2011,7 @@ __global__ __launch_bounds__(PHASE == 2 ? 64 : (PHASE == 3 ? kTailRT : (PHASE ==
     st.merges = merges;
     st.overflow = 0;
     rb.stats[frame] = st;
-    if (PHASE == 3 && rx.res) rx.res[frame * 4 + 2] = static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - t_res;
+    if ((PHASE == 3 || PHASE == 5) && rx.res) rx.res[frame * 4 + 2] = static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - t_res;
     if (DBG && rx.dbg) {
       unsigned long long* d = rx.dbg + static_cast<size_t>(frame) * kDbgSlots;
       const unsigned long long t_end = DPX_STAMP();

@@ -68,7 +68,7 @@ struct CoreBufs {
   uint32_t* cgrow;        // [B][C]   indexed by core ID: grow index + 1 (k_regsim)
   uint32_t* cursor;       // [B][4]   allocation cursors of corepairs / oedges, planar cells of the frame
   uint32_t* cellq;        // [B][C]   k_cellgrow: (grow + 1) << 4 | in-edge bits
-  int* order_task;        // [B]      task counter of k_order
+  int* order_task;        // [B][4]   task counters of k_order and k_seg_accum
   int T, logT, Cpad;
 };
 
@@ -176,8 +176,7 @@ __global__ __launch_bounds__(256) void k_core_init(Params prm, CoreBufs cb) {
     cc_store(cb.cursor + 4 * frame + 1, 0u);
     cc_store(cb.cursor + 4 * frame + 2, 0u);
     cc_store(cb.cursor + 4 * frame + 3, 0u);
-    __hip_atomic_store(cb.order_task + 2 * frame, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(cb.order_task + 2 * frame + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int k = 0; k < 4; ++k) __hip_atomic_store(cb.order_task + 4 * frame + k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1124,7 +1123,7 @@ struct OrderBufs {
   const uint32_t* biglist;  // [B][pcap]
   const int* hdr;           // [B][48]
   uint32_t* queue;          // [B][C]
-  int* task;                // [B][2] task counters: waves' tasks, workgroups' tasks (zeroed by k_core_init)
+  int* task;                // [B][4] task counters: waves' tasks, workgroups' tasks (+ k_seg_accum's two) (zeroed by k_core_init)
   unsigned long long* dbg;
   int pcap;
 };
@@ -1172,8 +1171,8 @@ __global__ __launch_bounds__(kOrderWaves * 64) void k_order(Params prm, OrderBuf
     int* ctl = reinterpret_cast<int*>(bmap + kHugeHash);  // 0 task, 8.. per-wave winner counts
     constexpr uint32_t kRingMask = kHugeRing - 1u;
     const uint32_t notme = ~(1u << opp) & 0xFu;
-    for (;;) {
-      if (tid == 0) ctl[0] = atomicAdd(ob.task + 2 * frame + 1, 1);
+    for (int guard = 0; guard <= nhuge; ++guard) {
+      if (tid == 0) ctl[0] = atomicAdd(ob.task + 4 * frame + 1, 1);
       for (int i = tid; i < kHugeHash; i += kOrderWaves * 64) bmap[i] = 0xFFFFFFFFu;
       __syncthreads();
       const int t = ctl[0];
@@ -1261,9 +1260,9 @@ __global__ __launch_bounds__(kOrderWaves * 64) void k_order(Params prm, OrderBuf
     }
     return;
   }
-  for (;;) {
+  for (int guard = 0; guard <= ntasks; ++guard) {  // (every task loop is bounded: a wave takes each task at most once)
     int t = 0;
-    if (lane == 0) t = atomicAdd(ob.task + 2 * frame, 1);
+    if (lane == 0) t = atomicAdd(ob.task + 4 * frame, 1);
     t = __builtin_amdgcn_readfirstlane(t);
     if (t >= ntasks) break;
     if (t < nbig) {
@@ -1376,6 +1375,190 @@ __global__ __launch_bounds__(kOrderWaves * 64) void k_order(Params prm, OrderBuf
   }
   if (DBG && ob.dbg && lane == 0)
     atomicMax(ob.dbg + static_cast<size_t>(frame) * kDbgSlots + 2, static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - t_start);
+}
+
+// ---- segment sums and fits, chip-wide (the tail's P2 and P3 of dpx_regions2.h taken out of the frame's workgroup) ----------
+// A candidate segment's nine sums are nine strictly sequential float chains in queue order, the seed counted twice
+// (plane_extractor.cpp:318-323); different segments are independent.  k_seg_accum<false>: a wave per segment, pulled from a
+// counter (64-entry chunks staged through LDS, the next chunk's records in flight while the chains run).  k_seg_accum<true>:
+// a HUGE segment (>= kHugeMin cells — a clean 4K frame has one plane of 70 000) takes a workgroup: three producer waves gather
+// the records of 64-cell chunks into a ring of LDS buffers, twelve chunks per round, while wave 0 does nothing but read them
+// back and add — about 6 cycles per cell instead of 30.
+struct TailBufs {
+  const dpx_cell* cells;   // [B][C]
+  const uint32_t* queue;   // [B][C]
+  const uint4* cand_grow;  // [B][pcap]
+  const uint32_t* biglist; // [B][pcap]
+  const int* hdr;          // [B][48]
+  float* cand;             // [B][pcap][12] sums(9), n_pts, grow index, (accepted id: the tail launch)
+  float* candfit;          // [B][pcap][12] mean(3), normal(3), d, mse, score, ok
+  int* task;               // [B][4]: 2 = segments of k_seg_accum<false>, 3 = of k_seg_accum<true>
+  int pcap;
+};
+constexpr int kAccWaves = 4, kAccStage = 64;
+constexpr int kAccRound = 12, kAccRing = 2 * kAccRound;  // chunks per round of the huge-segment form, buffers in its ring
+
+template <bool HUGE>
+__global__ __launch_bounds__(kAccWaves * 64) void k_seg_accum(Params prm, TailBufs tb) {
+  const int frame = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int C = prm.C;
+  const size_t fo = static_cast<size_t>(frame) * C;
+  const dpx_cell* cells = tb.cells + fo;
+  const float4* cf4 = reinterpret_cast<const float4*>(cells);
+  const uint32_t* queue = tb.queue + fo;
+  const uint4* cand_grow = tb.cand_grow + static_cast<size_t>(frame) * tb.pcap;
+  float* cand = tb.cand + static_cast<size_t>(frame) * tb.pcap * 12;
+  const int* hdr = tb.hdr + static_cast<size_t>(frame) * 48;
+  const int ncand = hdr[3], nhuge = hdr[kHdrHuge];
+  constexpr int kStage = kAccStage;
+  if constexpr (!HUGE) {
+    __shared__ __align__(16) float s_stage[kAccWaves][kStage * 9];  // (read back 16 bytes at a time)
+    float* st = s_stage[wid];
+    for (int guard = 0; guard <= ncand; ++guard) {  // (a wave can take at most every segment once)
+      int ci = 0;
+      if (lane == 0) ci = atomicAdd(tb.task + 4 * frame + 2, 1);
+      ci = __builtin_amdgcn_readfirstlane(ci);
+      if (ci >= ncand) break;
+      const uint4 cg = cand_grow[ci];
+      const int gi = static_cast<int>(cg.x), gs = static_cast<int>(cg.y), ge = static_cast<int>(cg.z);
+      if (__builtin_amdgcn_readfirstlane(ge - gs) < kHugeMin) {  // (the huge ones are the other launch's)
+      const int comp = lane < 9 ? lane : 0;
+      float acc = reinterpret_cast<const float*>(cells)[static_cast<size_t>(queue[gs]) * 16 + comp];  // the seed, counted twice
+      float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa, pc = pa;
+      if (gs + lane < ge) {
+        const size_t v = queue[gs + lane];
+        pa = cf4[v * 4 + 0]; pb = cf4[v * 4 + 1]; pc = cf4[v * 4 + 2];
+      }
+      for (int base = gs; base < ge; base += kStage) {
+        const int cnt = (ge - base) < kStage ? (ge - base) : kStage;
+        if (lane < cnt) {  // staging is component-major: st[comp][entry]
+          float* d = st + lane;
+          d[0 * kStage] = pa.x; d[1 * kStage] = pa.y; d[2 * kStage] = pa.z; d[3 * kStage] = pa.w; d[4 * kStage] = pb.x;
+          d[5 * kStage] = pb.y; d[6 * kStage] = pb.z; d[7 * kStage] = pb.w; d[8 * kStage] = pc.x;
+        }
+        wave_sync();
+        {
+          const int nx = base + kStage + lane;
+          if (nx < ge) {
+            const size_t v = queue[nx];
+            pa = cf4[v * 4 + 0]; pb = cf4[v * 4 + 1]; pc = cf4[v * 4 + 2];
+          }
+        }
+        if (lane < 9) {
+          const float4* row = reinterpret_cast<const float4*>(st + comp * kStage);
+          float t[kStage];
+#pragma unroll
+          for (int q = 0; q < kStage / 4; ++q) {
+            const float4 x = row[q];
+            t[4 * q] = x.x; t[4 * q + 1] = x.y; t[4 * q + 2] = x.z; t[4 * q + 3] = x.w;
+          }
+          if (cnt == kStage) {
+#pragma unroll
+            for (int q = 0; q < kStage; ++q) acc = acc + t[q];
+          } else {
+#pragma unroll
+            for (int q = 0; q < kStage; ++q)
+              if (q < cnt) acc = acc + t[q];
+          }
+        }
+        wave_sync();
+      }
+      float* co = cand + static_cast<size_t>(ci) * 12;
+      if (lane < 9) co[lane] = acc;
+      if (lane == 9) co[9] = __int_as_float((ge - gs + 1) * prm.n);
+      if (lane == 10) co[10] = __int_as_float(gi);
+      }
+    }
+  } else {
+    if (nhuge == 0) return;
+    __shared__ __align__(16) float s_ring[kAccRing][kStage * 9];
+    __shared__ int s_task;
+    const uint32_t* biglist = tb.biglist + static_cast<size_t>(frame) * tb.pcap;
+    for (int guard = 0; guard <= nhuge; ++guard) {
+      __syncthreads();
+      if (tid == 0) s_task = atomicAdd(tb.task + 4 * frame + 3, 1);
+      __syncthreads();
+      const int t = s_task;
+      if (t >= nhuge) break;
+      const int ci = static_cast<int>(biglist[tb.pcap - 1 - t]);
+      const uint4 cg = cand_grow[ci];
+      const int gi = static_cast<int>(cg.x), gs = static_cast<int>(cg.y), ge = static_cast<int>(cg.z);
+      const int nchunks = (ge - gs + kStage - 1) / kStage;
+      const int comp = lane < 9 ? lane : 0;
+      float acc = 0.f;
+      if (wid == 0) acc = reinterpret_cast<const float*>(cells)[static_cast<size_t>(queue[gs]) * 16 + comp];  // the seed, counted twice
+      // round r: the producers fill chunks [12 r, 12 r + 12) while wave 0 adds chunks [12 (r - 1), 12 r)
+      const int nrounds = (nchunks + kAccRound - 1) / kAccRound;
+      for (int r = 0; r <= nrounds; ++r) {
+        if (wid > 0 && r < nrounds) {
+          // this wave's four chunks of the round: all queue loads, then all record loads, then the LDS writes
+          float4 pa[4], pb[4], pc[4];
+          int ck[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            ck[j] = r * kAccRound + (wid - 1) * 4 + j;
+            const int e = gs + ck[j] * kStage + lane;
+            const bool in = ck[j] < nchunks && e < ge;
+            const size_t v = in ? queue[e] : 0u;
+            pa[j] = make_float4(0.f, 0.f, 0.f, 0.f); pb[j] = pa[j]; pc[j] = pa[j];
+            if (in) { pa[j] = cf4[v * 4 + 0]; pb[j] = cf4[v * 4 + 1]; pc[j] = cf4[v * 4 + 2]; }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (ck[j] < nchunks) {
+              float* d = s_ring[ck[j] % kAccRing] + lane;
+              d[0 * kStage] = pa[j].x; d[1 * kStage] = pa[j].y; d[2 * kStage] = pa[j].z; d[3 * kStage] = pa[j].w; d[4 * kStage] = pb[j].x;
+              d[5 * kStage] = pb[j].y; d[6 * kStage] = pb[j].z; d[7 * kStage] = pb[j].w; d[8 * kStage] = pc[j].x;
+            }
+        }
+        if (wid == 0 && r > 0 && lane < 9) {
+          for (int k = (r - 1) * kAccRound; k < r * kAccRound && k < nchunks; ++k) {
+            const int cnt = (ge - gs - k * kStage) < kStage ? (ge - gs - k * kStage) : kStage;
+            const float4* row = reinterpret_cast<const float4*>(s_ring[k % kAccRing] + comp * kStage);
+            float tv[kStage];
+#pragma unroll
+            for (int q = 0; q < kStage / 4; ++q) {
+              const float4 x = row[q];
+              tv[4 * q] = x.x; tv[4 * q + 1] = x.y; tv[4 * q + 2] = x.z; tv[4 * q + 3] = x.w;
+            }
+            if (cnt == kStage) {
+#pragma unroll
+              for (int q = 0; q < kStage; ++q) acc = acc + tv[q];
+            } else {
+#pragma unroll
+              for (int q = 0; q < kStage; ++q)
+                if (q < cnt) acc = acc + tv[q];
+            }
+          }
+        }
+        __syncthreads();
+      }
+      float* co = cand + static_cast<size_t>(ci) * 12;
+      if (wid == 0) {
+        if (lane < 9) co[lane] = acc;
+        if (lane == 9) co[9] = __int_as_float((ge - gs + 1) * prm.n);
+        if (lane == 10) co[10] = __int_as_float(gi);
+      }
+    }
+  }
+}
+
+// grid (ceil(pcap / 256), B): CellSegmentStat::fitPlane of every candidate segment (plane_extractor.cpp:333-337), one thread each
+__global__ __launch_bounds__(256) void k_seg_fit(Params prm, TailBufs tb) {
+  const int frame = blockIdx.y;
+  const int ci = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
+  const int ncand = tb.hdr[static_cast<size_t>(frame) * 48 + 3];
+  if (ci >= ncand) return;
+  const float* co = tb.cand + (static_cast<size_t>(frame) * tb.pcap + ci) * 12;
+  float s[3] = {co[0], co[1], co[2]}, pp[6] = {co[3], co[4], co[5], co[6], co[7], co[8]};
+  PlaneFit fit;
+  fit_plane(s, pp, __float_as_int(co[9]), fit);
+  float* cf = tb.candfit + (static_cast<size_t>(frame) * tb.pcap + ci) * 12;
+  cf[0] = fit.mean[0]; cf[1] = fit.mean[1]; cf[2] = fit.mean[2];
+  cf[3] = fit.normal[0]; cf[4] = fit.normal[1]; cf[5] = fit.normal[2];
+  cf[6] = fit.d; cf[7] = fit.mse; cf[8] = fit.score;
+  cf[9] = __int_as_float(fit.score > prm.min_score ? 1 : 0);
 }
 
 }  // namespace dpx
