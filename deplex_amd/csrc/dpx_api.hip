@@ -83,6 +83,9 @@ struct dpx_handle_s {
   int sort_pad = 0;                          // tier 2: slots of the in-LDS seed-list sort (power of two >= C)
   // variant switches, read from the environment at create (tests and diagnostics)
   bool opt_nofuse = false, opt_labels_v1 = false, opt_cloud_nolds = false, opt_prep_v1 = false;
+  bool opt_sort_bitonic = true;              // tiers 1/0: the frame-wide bitonic seed-list sort of dpx_binsort.h; false (DPX_SORT_COUNTING=1) = the
+                                             // core path's counting sort on cell keys — measured slower there (1280x960 x 256: 114 k against 211 k frames/s:
+                                             // a clean frame has ~10 000 cells in ONE bin, one workgroup's sort), kept as a cross-check
   int opt_csr_chunk = 64;
   int Cpad = 0;                              // tiers 1/0: sort slots per frame (power of two >= C)
   unsigned long long* d_sort_keys = nullptr;  // [B][Cpad]
@@ -108,6 +111,7 @@ struct dpx_handle_s {
   uint4* d_oedges = nullptr;                  // [B][4C] one-way edges with their target core's data
   uint2* d_crec = nullptr;                    // [B][C] by core ID: first one-way edge, number of edges
   float* d_candfit = nullptr;                 // [B][pcap][12] fits of the candidate segments (k_seg_fit)
+  uint32_t* d_pbcnt_own = nullptr;            // cell-level tiers 1/0: [B][bins] counters of the counting sort
   uint4* d_lists = nullptr;                   // [B][C][2] seed lists, one 32-byte entry per (core, bin) pair
   // staging for the host-pointer API (lazy)
   void* d_in = nullptr;
@@ -167,6 +171,7 @@ void free_all(dpx_handle h) {
   hipFree(h->d_oedges);
   hipFree(h->d_crec);
   hipFree(h->d_candfit);
+  hipFree(h->d_pbcnt_own);
   hipFree(h->d_lists);
   hipFree(h->d_sort_keys);
   hipFree(h->d_bin_off);
@@ -379,6 +384,21 @@ dpx::CoreBufs core_bufs(dpx_handle h) {
 
 // seed lists of the sorted region tiers (dpx_binsort.h): keys -> bitonic network -> per-bin cell lists
 void launch_binsort(dpx_handle h, const dpx::Params& prm, hipStream_t s) {
+  if (!h->opt_sort_bitonic) {
+    // counting sort over the bins, then every bin's segment sorted by (mse, cell) in LDS (dpx_regions3.h)
+    const int nbins = prm.hist_B * prm.hist_B, B = prm.batch;
+    const dim3 cell_grid(static_cast<unsigned>((prm.C + 255) / 256), static_cast<unsigned>(B));
+    dpx::CoreBufs cb{};
+    cb.keys = h->d_sort_keys; cb.bin_off = h->d_bin_off; cb.pbcnt = h->d_pbcnt; cb.Cpad = h->Cpad;
+    (void)hipMemsetAsync(h->d_pbcnt, 0, static_cast<size_t>(B) * nbins * 4, s);
+    hipLaunchKernelGGL(dpx::k_cell_bincount, cell_grid, dim3(256), 0, s, prm, h->d_meta, h->d_pbcnt);
+    hipLaunchKernelGGL(dpx::k_bin_scan, dim3(static_cast<unsigned>(B)), dim3(64), 0, s, prm, cb);
+    hipLaunchKernelGGL(dpx::k_cell_scatter, cell_grid, dim3(256), 0, s, prm, h->d_meta, h->d_mse_c, h->d_pbcnt, h->d_bin_off, h->d_sort_keys, h->Cpad);
+    const int sort_wgs = std::max(4, std::min(std::min(64, nbins), 2048 / std::max(1, B)));
+    const int cap = std::max(64, std::min(prm.C, dpx::kCellSortMax));
+    hipLaunchKernelGGL((dpx::k_bin_sort<true>), dim3(static_cast<unsigned>(std::min(sort_wgs, nbins)), static_cast<unsigned>(B)), dim3(dpx::kCellSortT), static_cast<size_t>(cap) * 8, s, prm, cb, h->d_order, cap);
+    return;
+  }
   const int Cpad = h->Cpad, B = prm.batch;
   const long long slots = static_cast<long long>(B) * Cpad;
   const unsigned g256 = static_cast<unsigned>((slots + 255) / 256);
@@ -506,7 +526,7 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
     hipLaunchKernelGGL(dpx::k_bin_scan, dim3(static_cast<unsigned>(batch)), dim3(64), 0, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_pair_scatter, g_tab, dim3(256), 0, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_edge_scatter, cell_grid, dim3(256), 0, s, prm, cb);
-    hipLaunchKernelGGL(dpx::k_bin_sort, dim3(static_cast<unsigned>(std::min(sort_wgs, nbins)), static_cast<unsigned>(batch)), dim3(dpx::kBinSortT), 0, s, prm, cb);
+    hipLaunchKernelGGL((dpx::k_bin_sort<false>), dim3(static_cast<unsigned>(std::min(sort_wgs, nbins)), static_cast<unsigned>(batch)), dim3(dpx::kBinSortT), static_cast<size_t>(dpx::kBinSortMax) * 8, s, prm, cb, static_cast<uint32_t*>(nullptr), dpx::kBinSortMax);
   }
   if (total > 0 && (h->regions_tier == 1 || h->regions_tier == 0) && !h->cores && !skip_r) launch_binsort(h, prm, s);
   if (prof) DPX_HIP(hipEventRecord(ev[3], s));
@@ -957,6 +977,7 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
   h->opt_labels_v1 = std::getenv("DPX_LABELS_V1") != nullptr;
   h->opt_cloud_nolds = std::getenv("DPX_CLOUD_NOLDS") != nullptr;
   h->opt_prep_v1 = std::getenv("DPX_PREP_V1") != nullptr;
+  h->opt_sort_bitonic = std::getenv("DPX_SORT_COUNTING") == nullptr;
   // preparation and grow in one launch (tier 2, lean preparation, C small enough for its key hand-over; +1 % in long runs,
   // +2.5 % in 20-step ones); DPX_PREP_GROW_SPLIT restores the two launches (test hook)
   h->opt_prep_grow_fused = !h->opt_prep_v1 && static_cast<long long>(C) <= dpx::kFusedMaxCells && !std::getenv("DPX_PREP_GROW_SPLIT");  // test hook: tier-2 preparation with the whole image in LDS
@@ -1041,7 +1062,11 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
       const dpx::R2Layout l0 = dpx::r2_layout(0, Ci, nbi, nh);
       const bool fits_cores = nb < 4600 && C >= 1 && C < (size_t(1) << dpx::kKeyCellBits) && l0.tail_end <= kLdsLimit &&
                               dpx::s3_layout(nbi, Ci).end <= kLdsLimit && dpx::order_lds_bytes(Ci) + 8192 <= kLdsLimit;
-      if (fits_cores && (force_cores || (!named_old && h->regions_tier != 2))) {
+      // default: frames beyond tier 1's capacity (the 4K class: twice as fast there).  Mid-size frames (1280x960) keep the
+      // cell-level tiers: on frames with thousands of one-way edges the core path's sequence is the slower one
+      const dpx::R2Layout l1c = dpx::r2_layout(1, Ci, nbi, nh);
+      const bool big = !(C < 65000 && std::max<size_t>(l1c.tail_end, l1c.grow_end) <= kLdsLimit);
+      if (fits_cores && (force_cores || (!named_old && h->regions_tier != 2 && big))) {
         h->cores = true;
         h->core_logT = 6;
         while ((size_t(1) << h->core_logT) < 2 * C) ++h->core_logT;
@@ -1085,6 +1110,8 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
   if (h->regions_tier == 1 || h->regions_tier == 0) {
     A(dev_alloc(&h->d_sort_keys, B * static_cast<size_t>(h->Cpad)));
     A(dev_alloc(&h->d_bin_off, B * static_cast<size_t>(nb + 1)));
+    if (!h->cores) A(dev_alloc(&h->d_pbcnt_own, B * static_cast<size_t>(nb)));
+    if (!h->cores) h->d_pbcnt = h->d_pbcnt_own;
   }
   if (h->regions_tier == 0) {
     A(dev_alloc(&h->d_gqpos, B * C));  // (the core path's tail still uses it: bit row of the merge walk's wide rows)
@@ -1146,6 +1173,12 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->refine_lds)) != hipSuccess)
           rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
     }
+  }
+  if (rc == DPX_OK && (h->regions_tier == 1 || h->regions_tier == 0) && !h->cores && !h->opt_sort_bitonic &&
+      static_cast<size_t>(std::min(static_cast<int>(C), dpx::kCellSortMax)) * 8 > 48 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_bin_sort<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            std::min(static_cast<int>(C), dpx::kCellSortMax) * 8) != hipSuccess)
+      rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
   }
   if (rc == DPX_OK && h->cores && h->lds3_order + 8192 > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_order<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds3_order)) != hipSuccess ||
@@ -1240,7 +1273,10 @@ int dpx_process_depth_batch_cells(dpx_handle h, const uint16_t* depth, int32_t b
     return fail(DPX_ERR_ARG, "batch " + std::to_string(batch) + " exceeds max_batch " + std::to_string(h->max_batch));
   if (h->cfg.ransac_refinement) return fail(DPX_ERR_ARG, "cell-level output is not defined with ransac_refinement (it edits single pixels)");
   if (planes_total) *planes_total = 0;
-  if (batch == 0) return DPX_OK;
+  if (batch == 0) {  // an empty batch has no planes: dpx_get_packed_planes answers 0 records (no stale total of an earlier call)
+    h->cells_stage_total = 0;
+    return DPX_OK;
+  }
   if (!depth || !cell_labels) return fail(DPX_ERR_ARG, "null buffer");
   if (planes && planes_cap < 0) return fail(DPX_ERR_ARG, "negative planes_cap");
   DPX_HIP(hipSetDevice(h->device));
@@ -1288,6 +1324,10 @@ int dpx_process_depth_batch_cells(dpx_handle h, const uint16_t* depth, int32_t b
 
 int dpx_get_packed_planes(dpx_handle h, dpx_plane* planes, int64_t planes_cap, int64_t* planes_total) {
   if (!h) return fail(DPX_ERR_ARG, "null handle");
+  if (h->cells_stage_total == 0) {  // (also the empty batch, which never allocated the staging)
+    if (planes_total) *planes_total = 0;
+    return DPX_OK;
+  }
   if (!h->h_cells_stage || h->cells_stage_total < 0) return fail(DPX_ERR_ARG, "no cell-level call with plane counts precedes this one");
   if (planes_total) *planes_total = h->cells_stage_total;
   if (planes_cap < 0 || (planes_cap > 0 && !planes)) return fail(DPX_ERR_ARG, "bad plane buffer");
@@ -1476,6 +1516,7 @@ int dpx_get_options(dpx_handle h, char* buf, int32_t cap) {
   o += std::string(";split=") + (h->regions_split ? "1" : "0") + ";stream=" + (h->stream_mode ? "1" : "0");
   o += std::string(";prep_grow_fused=") + (h->opt_prep_grow_fused ? "1" : "0") + ";fused_labels=" + (h->opt_nofuse ? "0" : "1");
   o += std::string(";labels_v1=") + (h->opt_labels_v1 ? "1" : "0") + ";cloud_lds=" + (h->opt_cloud_nolds ? "0" : "1") + ";prep_v1=" + (h->opt_prep_v1 ? "1" : "0");
+  o += std::string(";sort=") + (h->opt_sort_bitonic ? "bitonic" : "counting");
   o += ";csr_chunk=" + std::to_string(h->opt_csr_chunk) + ";cells=" + std::to_string(h->prm.C) + ";pcap=" + std::to_string(h->pcap);
   const int n = static_cast<int>(std::min<size_t>(o.size(), static_cast<size_t>(cap) - 1));
   std::memcpy(buf, o.data(), static_cast<size_t>(n));
@@ -1522,7 +1563,7 @@ int dpx_debug_cores_phases(dpx_handle h, int32_t frame, uint64_t* out32) {
   return DPX_OK;
 }
 
-int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_t* out24) {
+int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_t* out32) {
   if (!h) return fail(DPX_ERR_ARG, "null handle");
   DPX_HIP(hipSetDevice(h->device));
   if (enable && !h->d_dbg) {
@@ -1539,10 +1580,10 @@ int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_
       DPX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds2_bytes)));
     }
   }
-  if (out24) {
+  if (out32) {
     if (!h->d_dbg || frame < 0 || frame >= h->max_batch) return fail(DPX_ERR_ARG, "diagnostics not enabled or bad frame");
     DPX_HIP(hipStreamSynchronize(h->last_stream));
-    DPX_HIP(hipMemcpy(out24, h->d_dbg + static_cast<size_t>(frame) * dpx::kDbgSlots, dpx::kDbgSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    DPX_HIP(hipMemcpy(out32, h->d_dbg + static_cast<size_t>(frame) * dpx::kDbgSlots, dpx::kDbgSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   }
   if (!enable && h->d_dbg) {
     hipFree(h->d_dbg);

@@ -384,12 +384,19 @@ __global__ __launch_bounds__(64) void k_bin_scan(Params prm, CoreBufs cb) {
 // further load for a core of up to four bins (a core with one-way edges out: two pairs, first edge, number of edges).  Segments of up to kBinSortMax keys are sorted in LDS (all-ascending bitonic
 // network on exactly n keys, as in dpx_regions2.h's preparation), longer ones in place in global memory by the same
 // workgroup.
-constexpr int kBinSortT = 256, kBinSortMax = 4096;
-__global__ __launch_bounds__(kBinSortT) void k_bin_sort(Params prm, CoreBufs cb) {
+constexpr int kBinSortT = 256, kBinSortMax = 4096;       // the core path's form: pairs per bin are few
+constexpr int kCellSortT = 1024, kCellSortMax = 16384;   // the cell-level form: a clean frame has most of its cells in one bin
+// CELLS = the cell-level tiers' form: the sorted segment's cell ids go to `order` (cb.keys, cb.bin_off, cb.Cpad are all it reads).
+// `cap` = keys the launch's dynamic LDS holds (8 bytes each).
+template <bool CELLS>
+__global__ __launch_bounds__(CELLS ? kCellSortT : kBinSortT) void k_bin_sort(Params prm, CoreBufs cb, uint32_t* __restrict__ order, int cap) {
+  constexpr int kBinSortT = CELLS ? kCellSortT : dpx::kBinSortT;  // (this launch's workgroup size)
+  const int kBinSortMax = cap;
   const int frame = blockIdx.y, tid = threadIdx.x;
   const int nb = prm.hist_B * prm.hist_B;
   const uint32_t* bo = cb.bin_off + static_cast<size_t>(frame) * (nb + 1);
-  __shared__ unsigned long long sk[kBinSortMax];
+  extern __shared__ __align__(16) unsigned char sk_raw[];
+  unsigned long long* sk = reinterpret_cast<unsigned long long*>(sk_raw);
   for (int bin = blockIdx.x; bin < nb; bin += gridDim.x) {  // (a few workgroups per frame: most bins are empty)
   const int s0 = static_cast<int>(bo[bin]), n = static_cast<int>(bo[bin + 1]) - s0;
   if (n <= 0) continue;
@@ -437,6 +444,10 @@ __global__ __launch_bounds__(kBinSortT) void k_bin_sort(Params prm, CoreBufs cb)
   for (int i = tid; i < n; i += kBinSortT) {
     const unsigned long long key = in_lds ? sk[i] : __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t cell = static_cast<uint32_t>(key & kCellMask);
+    if constexpr (CELLS) {
+      order[fo + s0 + i] = cell;
+      continue;
+    }
     const uint32_t r = cb.parent[fo + cell];
     const uint32_t ps = cb.pstart[fo + r], np = cb.npairs[fo + r];
     uint4 pr = make_uint4(0u, 0u, 0u, 0u);
@@ -454,6 +465,45 @@ __global__ __launch_bounds__(kBinSortT) void k_bin_sort(Params prm, CoreBufs cb)
     cb.lists[2 * (fo + s0 + i) + 1] = pr;
   }
   }
+}
+
+// ---- the same counting sort for the cell-level tiers of dpx_regions2.h (seed lists of CELLS: bin, then MSE, then cell id) ----
+// k_cell_bincount: cells per bin; k_bin_scan: segment offsets; k_cell_scatter: every planar cell's (mse key << 19 | cell) into
+// its bin's segment; k_bin_sort_cells: each segment sorted, cell ids written to order[B][C].  Replaces the frame-wide bitonic
+// network of dpx_binsort.h (O(log^2 C) chip-wide passes over Cpad slots for keys whose top field is one of a few hundred bins).
+__global__ __launch_bounds__(256) void k_cell_bincount(Params prm, const uint32_t* __restrict__ meta, uint32_t* __restrict__ pbcnt) {
+  const int frame = blockIdx.y;
+  const int c = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
+  const int nb = prm.hist_B * prm.hist_B;
+  const int lane = threadIdx.x & 63;
+  int bin = -1;
+  if (c < prm.C) {
+    const uint32_t m = meta[static_cast<size_t>(frame) * prm.C + c];
+    const int bn = static_cast<int>(m >> META_BIN_SHIFT);
+    if ((m & F_UNASSIGNED) && bn >= 1 && bn - 1 < nb) bin = bn - 1;
+  }
+  unsigned long long todo = __ballot(bin >= 0);  // neighbouring cells mostly share their bin: one atomic per distinct bin of the wave
+  while (todo) {
+    const int l = static_cast<int>(__builtin_ctzll(todo));
+    const int b0 = __builtin_amdgcn_readlane(bin, l);
+    const unsigned long long same = __ballot(bin == b0) & todo;
+    if (lane == l) atomicAdd(pbcnt + static_cast<size_t>(frame) * nb + b0, static_cast<uint32_t>(__popcll(same)));
+    todo &= ~same;
+  }
+}
+__global__ __launch_bounds__(256) void k_cell_scatter(Params prm, const uint32_t* __restrict__ meta, const float* __restrict__ mse_c,
+                                                      uint32_t* __restrict__ pbcnt, const uint32_t* __restrict__ bin_off,
+                                                      unsigned long long* __restrict__ keys, int Cpad) {
+  const int frame = blockIdx.y;
+  const int c = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
+  if (c >= prm.C) return;
+  const int nb = prm.hist_B * prm.hist_B;
+  const size_t fo = static_cast<size_t>(frame) * prm.C;
+  const uint32_t m = meta[fo + c];
+  const int bn = static_cast<int>(m >> META_BIN_SHIFT);
+  if (!((m & F_UNASSIGNED) && bn >= 1 && bn - 1 < nb)) return;
+  const uint32_t at = bin_off[static_cast<size_t>(frame) * (nb + 1) + bn - 1] + atomicAdd(pbcnt + static_cast<size_t>(frame) * nb + bn - 1, 1u);
+  keys[static_cast<size_t>(frame) * Cpad + at] = (static_cast<unsigned long long>(sort_mse_key(mse_c[fo + c])) << kCellBits) | static_cast<unsigned long long>(c);
 }
 
 // ---- the sequence of grows --------------------------------------------------------------------------------------------

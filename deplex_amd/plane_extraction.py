@@ -307,6 +307,17 @@ class Pipeline:
         and must not be touched until sync()."""
         if depth.dtype != np.uint16 or not depth.flags.c_contiguous or out.dtype != np.int32 or not out.flags.c_contiguous:
             raise TypeError("depth must be C-contiguous uint16, out C-contiguous int32")
+        # The C side queues asynchronous copies of batch*H*W*2 bytes in and batch*H*W*4 (or batch*nv*nh*4) bytes out: a wrong
+        # shape would be read or written out of bounds in host memory after this call has returned.
+        if depth.ndim != 3 or tuple(depth.shape) != (self.batch, self.image_height, self.image_width):
+            raise TypeError(f"depth must have shape ({self.batch}, {self.image_height}, {self.image_width}), got {tuple(depth.shape)}")
+        if cells:
+            ex0 = self.slot(0)
+            want = self.batch * ex0.nv * ex0.nh
+        else:
+            want = self.batch * self.image_height * self.image_width
+        if out.size != want:
+            raise TypeError(f"out must hold {want} int32 values ({'cell labels' if cells else 'pixel labels'}), got {out.size}")
         batch = int(depth.shape[0])
         fn = _capi.lib().dpx_pipeline_submit_depth_cells_host if cells else _capi.lib().dpx_pipeline_submit_depth_host
         self._keep.append((depth, out))

@@ -50,8 +50,10 @@ def assert_planes_equal(gp, op):
         assert np.array_equal(gp[f], op[f]), f
 
 
-def full_compare(D, O, depth, intr, ocfg, batch_api=True, xyz_api=False):
-    """Runs a batch through the HIP path and every frame through the oracle; compares everything."""
+def full_compare(D, O, depth, intr, ocfg, batch_api=True, xyz_api=False, glibc=True):
+    """Runs a batch through the HIP path and every frame through the oracle; compares everything.  glibc: every frame also
+    against the oracle's glibc flavour — the maths the reference links (libs/dsyev/src/dsyevc3.c:66-72,
+    normals_histogram.cpp:35-37): identical label map, plane records within 1e-5 (north_star's tolerance)."""
     O.set_math("devmath")
     B, H, W = depth.shape
     ex = D.PlaneExtractor(H, W, to_cfg(D, ocfg), max_batch=B)
@@ -69,6 +71,18 @@ def full_compare(D, O, depth, intr, ocfg, batch_api=True, xyz_api=False):
         st = ex.frame_stats(k)
         assert (st["planar_cells"], st["grows"], st["activations"], st["segments"], st["merges"]) == \
                (ost["planar_cells"], ost["grows"], ost["activations"], ost["segments"], ost["merges"])
+        if glibc:
+            O.set_math("glibc")
+            try:
+                gl, _, gp, _, _ = O.process(ocfg, H, W, xyz, debug=True)
+            finally:
+                O.set_math("devmath")
+            assert np.array_equal(labels[k], gl), f"frame {k}: label map differs from the glibc-flavour oracle"
+            hp = ex.planes(k)
+            assert len(hp) == len(gp)
+            for f in ("mean", "normal", "d", "mse", "score"):
+                a, b = hp[f].astype(np.float64), gp[f].astype(np.float64)
+                assert np.all(np.abs(a - b) <= 1e-5 * np.maximum(1.0, np.abs(b))), f"frame {k}: plane {f} beyond 1e-5 of the glibc flavour"
     return labels
 
 
@@ -245,7 +259,7 @@ def test_ragged_and_tiny_images(D, oracle):
                     del os.environ[env]
 
 
-@pytest.mark.parametrize("env", ["DPX_FORCE_GLOBAL_STATE", "DPX_REGIONS_V1", "DPX_REGIONS_LEAN", "DPX_REGIONS_GSTATE", "DPX_NO_FASTDIV", "DPX_PLANEFIT_V1", "DPX_LABELS_V1", "DPX_REGIONS_NOSPLIT", "DPX_FUSED_LABELS", "DPX_PREP_V1", "DPX_PREP_GROW_SPLIT", "DPX_REGIONS_GSPLIT"])
+@pytest.mark.parametrize("env", ["DPX_FORCE_GLOBAL_STATE", "DPX_REGIONS_V1", "DPX_REGIONS_LEAN", "DPX_REGIONS_GSTATE", "DPX_NO_FASTDIV", "DPX_PLANEFIT_V1", "DPX_LABELS_V1", "DPX_REGIONS_NOSPLIT", "DPX_FUSED_LABELS", "DPX_PREP_V1", "DPX_PREP_GROW_SPLIT", "DPX_REGIONS_GSPLIT", "DPX_REGIONS_CORES"])
 def test_kernel_variants(D, oracle, env):
     """Every kernel variant must give the same bits: region growing with its per-cell state in global memory
     (used when a frame does not fit LDS), the v1 single-wave kernel, the lean LDS tier and the flag-byte-only tier (both
@@ -266,18 +280,20 @@ def test_kernel_variants(D, oracle, env):
         del os.environ[env]
 
 
-@pytest.mark.parametrize("env", [None, "DPX_CSR_CHUNK", "DPX_REGIONS_GSPLIT"])
+@pytest.mark.parametrize("env", [None, "DPX_CSR_CHUNK", "DPX_REGIONS_GSPLIT", "DPX_REGIONS_CORES", "DPX_REGIONS_V2", "DPX_SORT_COUNTING"])
 def test_large_frames(D, oracle, env):
     """BASELINE configs 3 and 5 in small: 1280x960 (lean LDS tier, hundreds of planes -> CSR merge walk) and one
     3840x2160 frame (82 944 cells: flag byte in LDS, queues in global memory, 32-bit indices, thousands of grows).
     DPX_REGIONS_GSPLIT: the 1280x960 frames through the split form of tier 0 (one-wave grow launch with a small scratch,
-    what the slots of a pipeline take for frames of this size)."""
+    what the slots of a pipeline take for frames of this size).  DPX_REGIONS_CORES: the 1280x960 frames through the
+    core-based path (dpx_regions3.h) — both have hundreds to a thousand grows over one-way edges ("irregular" events);
+    DPX_SORT_COUNTING: tier 1 seeded from the counting sort instead of the bitonic network."""
     if env:
         os.environ[env] = "1"  # every adjacency row takes the wide (bit-row) walk
     try:
         depth = np.stack([synth.synth_depth(960, 1280, seed=s) for s in (0, 6)])
         full_compare(D, oracle, depth, synth.intrinsics_for(960, 1280), oracle.default_config())
-        if env is None:
+        if env in (None, "DPX_REGIONS_V2"):  # (None: the core path, what frames of this size take; V2: the cell-level tier 0)
             # seed 0: ~1700 planes (CSR merge walk, isolated seeds); seed 1: ~220 planes (LDS merge path, wide BFS batches)
             depth = np.stack([synth.synth_depth(2160, 3840, seed=s) for s in (0, 1)])
             full_compare(D, oracle, depth, synth.intrinsics_for(2160, 3840), oracle.default_config())
@@ -1056,3 +1072,128 @@ def test_bench_refuses_to_report_when_a_rank_fails_parity():
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")], r.stdout
     assert "parity check failed" in (r.stderr + r.stdout)
+
+
+# ---- the core-based region path (dpx_regions3.h): what frames beyond tier 1's capacity take ------------------------------
+def test_core_path_cases(D, oracle):
+    """The core-based path forced (DPX_REGIONS_CORES=1) on frames the oracle does in milliseconds: the fixtures, ragged and
+    tiny grids, every grow a candidate (min cells 1), few histogram bins (pair segments beyond the LDS sort: 2 x 2 bins on a
+    4K quilt), one bin, frames whose grows cross hundreds of one-way edges, quilts of thousands of small cores."""
+    os.environ["DPX_REGIONS_CORES"] = "1"
+    try:
+        K = synth.read_K(synth.TUM_K)
+        it = tuple(float(v) for v in (K[0, 0], K[1, 1], K[0, 2], K[1, 2]))
+        Ki = synth.read_K(synth.ICL_K)
+        ii = tuple(float(v) for v in (Ki[0, 0], Ki[1, 1], Ki[0, 2], Ki[1, 2]))
+        assert D.PlaneExtractor(480, 640).options()["regions"] == "cores"
+        full_compare(D, oracle, synth.tum_stream(3), it, oracle.default_config())
+        full_compare(D, oracle, synth.load_png_u16(synth.ICL_PNG)[None], ii, oracle.config_from_ini(synth.ICL_INI))
+        full_compare(D, oracle, synth.synth_batch(2, 480, 640, seed0=2), synth.intrinsics_for(480, 640),
+                     oracle.default_config(min_region_growing_cells_activated=1, min_region_growing_candidate_size=1))
+        full_compare(D, oracle, synth.synth_batch(3, 240, 320, seed0=7), synth.intrinsics_for(240, 320), oracle.default_config(patch_size=4))
+        full_compare(D, oracle, synth.synth_batch(2, 333, 517, seed0=3), synth.intrinsics_for(333, 517), oracle.default_config(patch_size=7))
+        full_compare(D, oracle, synth.synth_batch(2, 30, 50, seed0=1), synth.intrinsics_for(30, 50), oracle.default_config())
+        full_compare(D, oracle, synth.synth_batch(2, 480, 640, seed0=2), synth.intrinsics_for(480, 640), oracle.default_config(histogram_bins_per_coord=1))
+        q = np.stack([synth.quilt_depth(960, 1280, seed=s) for s in (0, 5)])
+        full_compare(D, oracle, q, synth.intrinsics_for(960, 1280), oracle.default_config())
+        full_compare(D, oracle, q[:1], synth.intrinsics_for(960, 1280), oracle.default_config(histogram_bins_per_coord=3))
+        full_compare(D, oracle, synth.quilt_depth(2160, 3840, seed=2)[None], synth.intrinsics_for(2160, 3840),
+                     oracle.default_config(histogram_bins_per_coord=2), glibc=False)
+    finally:
+        del os.environ["DPX_REGIONS_CORES"]
+
+
+def test_core_path_copies_agree_under_load(D):
+    """32 copies of four 4K frames in one batch, three handles at once from three host threads: every copy of a frame must give
+    the same label map and statistics.  (The cores come from a lock-free union-find across all XCDs; a form of it that was not
+    linearizable lost a union in one frame of a hundred under exactly this load and nowhere else.)"""
+    import threading
+    h, w, B, nu = 2160, 3840, 32, 4
+    assert D.PlaneExtractor(h, w).options()["regions"] == "cores"
+    depth = np.concatenate([synth.synth_batch(nu, h, w, seed0=0)] * (B // nu))
+    intr = synth.intrinsics_for(h, w)
+    exs = [D.PlaneExtractor(h, w, max_batch=B) for _ in range(3)]
+    outs = [None] * 3
+
+    def run(i):
+        outs[i] = exs[i].process_depth_batch(depth, *intr)
+    for rep in range(2):
+        ths = [threading.Thread(target=run, args=(i,)) for i in range(3)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        for i in range(3):
+            for k in range(nu, B):
+                assert np.array_equal(outs[i][k], outs[i][k % nu]), (rep, i, k)
+                assert tuple(exs[i].frame_stats(k)) == tuple(exs[i].frame_stats(k % nu)), (rep, i, k)
+            assert np.array_equal(outs[i][:nu], outs[0][:nu])
+
+
+def test_pipeline_large_frames(D, oracle):
+    """dpx_pipeline at the sizes whose slots pick their region path by themselves: 1280x960 (tier 0 in split form: one-wave
+    grow launch) with groups of several submissions mixing pixel-label and cell-level outputs, and 1920x1080 (the core-based
+    path in stream mode); bit-exact against the oracle."""
+    import torch
+    dev = torch.device("cuda", 0)
+    oracle.set_math("devmath")
+    for (h, w, want) in ((960, 1280, "tier0-split"), (1080, 1920, "cores")):
+        depth = synth.synth_batch(2, h, w, seed0=0)
+        intr = synth.intrinsics_for(h, w)
+        ref = oracle.process_depth_batch(oracle.default_config(), depth, *intr)
+        pipe = D.Pipeline(h, w, D.Config(), batch=2, slots=2, group=3)
+        ex0 = pipe.slot(0)
+        assert ex0.options()["regions"] == want, ex0.options()
+        d_in = torch.from_numpy(depth.view(np.int16)).to(dev)
+        kinds = [False, False, True, True, False, True, True]  # True = cell level (a group holds one output form)
+        outs = [torch.full((2, ex0.nv, ex0.nh) if c else (2, h * w), -1, dtype=torch.int32, device=dev) for c in kinds]
+        for c, o in zip(kinds, outs):
+            (pipe.submit_depth_cells if c else pipe.submit_depth)(d_in.data_ptr(), 2, *intr, o.data_ptr())
+        pipe.sync()
+        for c, o in zip(kinds, outs):
+            got = o.cpu().numpy()
+            assert np.array_equal(ex0.expand_cell_labels(got) if c else got, ref), (h, w, c)
+        del pipe
+
+
+def test_pipeline_host_submission_checks_shapes(D):
+    """Pipeline.submit_depth_host refuses arrays of the wrong shape before anything is queued (the copies are asynchronous:
+    a short `out` would be written past its end after the call has returned)."""
+    pipe = D.Pipeline(240, 320, D.Config(), batch=2, slots=1, group=1)
+    intr = synth.intrinsics_for(240, 320)
+    good_d, good_o = np.zeros((2, 240, 320), np.uint16), np.zeros((2, 240 * 320), np.int32)
+    with pytest.raises(TypeError):
+        pipe.submit_depth_host(np.zeros((2, 240, 319), np.uint16), *intr, good_o)
+    with pytest.raises(TypeError):
+        pipe.submit_depth_host(np.zeros((1, 240, 320), np.uint16), *intr, good_o)
+    with pytest.raises(TypeError):
+        pipe.submit_depth_host(good_d, *intr, np.zeros((2, 240 * 320 - 1), np.int32))
+    with pytest.raises(TypeError):
+        pipe.submit_depth_host(good_d, *intr, np.zeros((2, 24, 31), np.int32), cells=True)
+    pipe.submit_depth_host(good_d, *intr, good_o)
+    pipe.submit_depth_host(good_d, *intr, np.zeros((2, 24, 32), np.int32), cells=True)
+    pipe.sync()
+
+
+def test_empty_cell_level_batch(D):
+    """process_depth_batch_cells on an empty batch returns empty records (it used to raise, or to report a stale
+    total of an earlier call)."""
+    ex = D.PlaneExtractor(240, 320, max_batch=2)
+    depth = synth.synth_batch(2, 240, 320, seed0=3)
+    ex.process_depth_batch_cells(depth, *synth.intrinsics_for(240, 320))
+    cl, planes = ex.process_depth_batch_cells(depth[:0], *synth.intrinsics_for(240, 320))
+    assert cl.shape[0] == 0 and planes == []
+
+
+def test_seeded_fuzz(D, oracle):
+    """tools/fuzz_parity.py's random cases (image sizes, ragged grids, patch sizes, configurations, input forms, kernel tiers,
+    pipelines with device- and host-buffer submissions; a third of them large frames) for a fixed seed, inside the suite the
+    driver runs: as many as fit ~50 s.  A failing case's parameter line goes into tests/golden/fuzz_regressions.txt."""
+    import sys
+    import time
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
+    import fuzz_parity as F
+    rng = np.random.default_rng(20261005)
+    t0, n = time.time(), 0
+    while n < 400 and time.time() - t0 < 50.0:
+        F.run_case(rng, big_fraction=0.3)
+        n += 1
+    assert n >= 40, f"only {n} cases in the time budget"

@@ -1,5 +1,6 @@
 """Randomised parity sweep: random image sizes, patch sizes, configurations, input forms and kernel tiers against the
-oracle (labels, cell records, plane records, statistics).  usage: fuzz_parity.py [cases] [seed] [share of large frames]"""
+oracle (labels, cell records, plane records, statistics).  usage: fuzz_parity.py [cases] [seed] [share of large frames]
+(tests/test_gpu_parity.py::test_seeded_fuzz runs run_case() for a fixed seed inside the driver's `pytest -m gpu`)"""
 import os, sys, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
@@ -68,14 +69,10 @@ def fuzz_pipeline(rng, depth, intr, ocfg, xyz):
     del pipe
 
 
-BIG_FRACTION = float(sys.argv[3]) if len(sys.argv) > 3 else 0.1  # share of large frames (up to ~4K-sized grids)
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-t0 = time.time()
-fails = 0
-for it in range(cases):
+def run_case(rng, big_fraction=0.1, verbose=False):
+    """One random case; raises on any difference.  Returns a one-line description (also attached to the exception)."""
     P = int(rng.choice([4, 8, 10, 10, 10, 6, 5, 7, 12, 16]))
-    big = rng.random() < BIG_FRACTION
+    big = rng.random() < big_fraction
     huge = big and rng.random() < 0.25
     nh = int(rng.integers(1, 400 if huge else (200 if big else 90)))
     nv = int(rng.integers(1, 230 if huge else (130 if big else 60)))
@@ -94,7 +91,9 @@ for it in range(cases):
         ov["min_region_planarity_score"] = float(rng.choice([0.3, 0.8]))
     if rng.random() < 0.15:
         ov["ransac_refinement"] = 1
-    env = str(rng.choice(["", "", "DPX_REGIONS_LEAN", "DPX_REGIONS_GSTATE", "DPX_REGIONS_NOSPLIT", "DPX_FUSED_LABELS", "DPX_REGIONS_V1", "DPX_PREP_GROW_SPLIT", "DPX_REGIONS_GSPLIT", "DPX_REGIONS_CORES", "DPX_REGIONS_CORES", "DPX_REGIONS_CORES"]))
+    envs = str(rng.choice(["", "", "DPX_REGIONS_LEAN", "DPX_REGIONS_GSTATE", "DPX_REGIONS_NOSPLIT", "DPX_FUSED_LABELS", "DPX_REGIONS_V1", "DPX_PREP_GROW_SPLIT",
+                           "DPX_REGIONS_GSPLIT", "DPX_REGIONS_CORES", "DPX_REGIONS_CORES", "DPX_REGIONS_CORES", "DPX_REGIONS_V2",
+                           "DPX_REGIONS_LEAN DPX_SORT_COUNTING", "DPX_REGIONS_GSTATE DPX_SORT_COUNTING"])).split()
     xyz = bool(rng.random() < 0.3)
     B = int(rng.integers(1, 4))
     seed = int(rng.integers(0, 10000))
@@ -105,22 +104,41 @@ for it in range(cases):
         kw = qk
     else:
         depth = np.stack([synth.synth_depth(h, w, seed=seed + k, **kw) for k in range(B)])
-    if os.environ.get("DPX_FUZZ_VERBOSE"):  # (to find a case that never returns: its parameters are printed first)
-        print(f"case {it}: {h}x{w} P={P} B={B} seed={seed} env={env} xyz={xyz} ov={ov} kw={kw}", flush=True)
-    if env:
-        os.environ[env] = "1"
+    desc = f"{h}x{w} P={P} B={B} seed={seed} env={' '.join(envs)} xyz={xyz} ov={ov} kw={kw}"
+    if verbose:  # (to find a case that never returns: its parameters are printed first)
+        print("case:", desc, flush=True)
+    for e in envs:
+        os.environ[e] = "1"
     try:
-        if rng.random() < 0.2 and env not in ("DPX_REGIONS_V1",):
+        if rng.random() < 0.2 and "DPX_REGIONS_V1" not in envs:
             fuzz_pipeline(rng, depth, synth.intrinsics_for(h, w), O.default_config(**ov), xyz)
         else:
-            T.full_compare(D, O, depth, synth.intrinsics_for(h, w), O.default_config(**ov), xyz_api=xyz)
+            T.full_compare(D, O, depth, synth.intrinsics_for(h, w), O.default_config(**ov), xyz_api=xyz, glibc=False)
     except Exception as e:  # noqa: BLE001
-        fails += 1
-        print(f"FAIL case {it}: {h}x{w} P={P} B={B} seed={seed} env={env} xyz={xyz} ov={ov} kw={kw}: {type(e).__name__}: {str(e)[:200]}", flush=True)
+        raise AssertionError(f"{desc}: {type(e).__name__}: {str(e)[:200]}") from e
     finally:
-        if env:
-            del os.environ[env]
-    if it % 20 == 19:
-        print(f"{it + 1} cases, {fails} failures, {time.time() - t0:.0f} s", flush=True)
-print(f"done: {cases} cases, {fails} failures")
-sys.exit(1 if fails else 0)
+        for e in envs:
+            del os.environ[e]
+    return desc
+
+
+def main():
+    big_fraction = float(sys.argv[3]) if len(sys.argv) > 3 else 0.1  # share of large frames (up to ~4K-sized grids)
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    t0 = time.time()
+    fails = 0
+    for it in range(cases):
+        try:
+            run_case(rng, big_fraction, verbose=bool(os.environ.get("DPX_FUZZ_VERBOSE")))
+        except AssertionError as e:
+            fails += 1
+            print(f"FAIL case {it}: {e}", flush=True)
+        if it % 20 == 19:
+            print(f"{it + 1} cases, {fails} failures, {time.time() - t0:.0f} s", flush=True)
+    print(f"done: {cases} cases, {fails} failures")
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -25,7 +25,8 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 S
   python3 tools/pmc_table.py $(ls $out/ic_$i/*counter_collection.csv $out/ic_$i/*/*counter_collection.csv 2>/dev/null | head -1) | grep -i "kernel\|planefit" > $out/${tag}_planefit_insts_pass$i.txt
   rm -rf $out/ic_$i
 done
-tools/ubench/mix_bench > $out/${tag}_ubench_mix.txt 2>&1
+[ -x tools/ubench/mix_bench ] || hipcc --offload-arch=gfx950 -O3 -o tools/ubench/mix_bench tools/ubench/mix.hip || echo "mix_bench not built: skipping"
+[ -x tools/ubench/mix_bench ] && tools/ubench/mix_bench > $out/${tag}_ubench_mix.txt 2>&1
 python3 tools/region_phases.py 2160 3840 4 > $out/${tag}_region_phases_4k.txt 2>/dev/null
 python3 tools/region_phases.py 960 1280 8 > $out/${tag}_region_phases_1280.txt 2>/dev/null
 python3 tools/region_time.py 4k 1280 640 > $out/${tag}_region_time.txt 2>/dev/null
