@@ -123,10 +123,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=-1)
     ap.add_argument("--batch", type=int, default=0, help="frames per step (default 64; --workload synth1280/synth640/synth4k: the BASELINE batch)")
     ap.add_argument("--unique", type=int, default=-1, help="distinct frames per input batch, tiled to --batch (synthetic workloads)")
-    # Pipeline shape.  0 = chosen from the run length: long runs (>= 100 steps) 4 slots x groups of 8 — one hardware queue
-    # per compute pipe, measured 1.65-1.70 M frames/s against 1.55-1.60 M with 16 slots and 1.52-1.55 M with 5 or 6 —
-    # short runs (the driver's 20 steps) 16 slots x groups of 5, which divides them into whole groups (1.24-1.28 M
-    # against 1.20-1.24 M with 4 slots and 1.08 M with groups of 8).  DESIGN.md section 5.
+    # Pipeline shape.  0 = the one default: 4 slots x groups of 8 — one hardware queue per compute pipe, measured 1.65-1.70 M
+    # frames/s against 1.55-1.60 M with 16 slots and 1.52-1.55 M with 5 or 6; the large-frame
+    # workloads have their own (BIG_WORKLOADS).
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DPX_BENCH_STREAMS", 0)), help="groups in flight (pipeline slots); 0 = auto")
     ap.add_argument("--group", type=int, default=int(os.environ.get("DPX_BENCH_GROUP", 0)), help="submissions per launch sequence (1..32); 0 = auto")
     ap.add_argument("--flush-after", default=os.environ.get("DPX_BENCH_FLUSH_AFTER", ""),
@@ -180,9 +179,12 @@ def main():
             dist.init_process_group(backend)
     import deplex_amd as D
 
-    long_run = args.steps >= 100
-    S = args.streams if args.streams > 0 else (big["streams"] if big else (4 if long_run else 16))  # groups in flight (pipeline slots), one stream each
-    G = max(1, min(32, args.group)) if args.group > 0 else (1 if big else (8 if long_run else 5))
+    # ONE default shape, whatever the run length: 4 slots x groups of 8 (one hardware queue per compute pipe of the command
+    # processor).  The driver's 20 timed steps are then 2.5 groups — `value` is that short run as it is,
+    # `sustained` the same shape over 2000 steps.  (Until round 3 short runs took 16 x 5 because that shape divides 20 steps
+    # into whole groups: a number shaped by the protocol, dropped.)
+    S = args.streams if args.streams > 0 else (big["streams"] if big else 4)  # groups in flight (pipeline slots), one stream each
+    G = max(1, min(32, args.group)) if args.group > 0 else (1 if big else 8)
     if big and args.inputs == 8:
         args.inputs = 2
     # The steps rotate over R distinct input batches (R divides the S*G output buffers, so buffer k always holds the
@@ -323,12 +325,12 @@ def main():
                 print(f"bench: {parity_err}", file=sys.stderr, flush=True)
             raise SystemExit("bench: parity check failed on at least one rank — refusing to report a number")
 
-    # ---- the long-run pipeline shape in the same record.  The driver times 20 steps (4 whole groups of 5 on 16 slots); the
-    # shape that sustains the highest rate keeps 4 slots x groups of 8 in flight and needs a few hundred steps to get
-    # there.  Same workload, same buffers-in-HBM rule, same barrier + synchronise bracket, MAX over ranks.
+    # ---- the same pipeline shape over a long run in the same record.  The driver times 20 steps; the pipeline needs a few
+    # hundred to reach its steady state.  Same workload, same buffers-in-HBM rule, same barrier + synchronise bracket, MAX
+    # over ranks.
     sustained = None
     if args.workload == "tum_stream" and args.input == "depth" and not args.no_sustained:
-        if long_run and not big:
+        if args.steps >= 1000 and not big:
             sus_elapsed, sus_steps, sus_S, sus_G = elapsed, args.steps, S, G
         else:
             sus_S, sus_G, sus_steps = 4, 8, args.sustained_steps
@@ -483,10 +485,18 @@ def main():
         # the whole path against the same roofline: SURVEY 8(d) algorithmic bytes per frame (input + 4 B of label per pixel)
         in_bpp = 12 if args.input == "cloud" else 2
         pipe_gbs = fps / world * N * (in_bpp + 4) / 1e9  # per GPU
+        pipe_traffic = None
+        ptfile = ROOT / "profiles" / "pipeline_traffic.json"
+        if ptfile.exists() and args.input == "depth":
+            try:
+                pipe_traffic = json.loads(ptfile.read_text()).get(args.workload, {}).get("hbm_bytes_per_frame")
+            except Exception:
+                pipe_traffic = None
         out["pipeline_roofline"] = {"bound": "hbm", "algorithmic_bytes_per_frame": N * (in_bpp + 4), "achieved": round(pipe_gbs, 1),
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pipe_gbs / HBM_PEAK_GBS, 4),
-                                    "note": "whole pipeline, input -> labels, per GPU; measured L2<->memory traffic is 2.42 MB per frame "
-                                            "(cell records and region images between the launches; profiles/r02f_pipeline_traffic.txt)"}
+                                    "traffic": pipe_traffic,
+                                    "note": "whole pipeline, input -> labels, per GPU; traffic = measured L2<->memory bytes per frame over all "
+                                            "kernels (2 x FETCH_SIZE + WRITE_SIZE, profiles/pipeline_traffic.json; null: not collected for this workload)"}
         if cloud_ms:
             out["roofline_cloud_input"] = {"kernel": "k_planefit_cloud_lds (organised xyz cloud -> per-cell moments + eigen plane fit), "
                                                      f"one launch per group of {G} submissions = {G * B} frames",

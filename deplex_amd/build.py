@@ -17,7 +17,7 @@ LIBS = ["-lz"]  # the PNG reader of the DepthImage path constructor (dpx_png.h) 
 
 
 def sources():
-    return [SRC / "dpx_api.hip", SRC / "dpx_kernels.h", SRC / "dpx_regions.h", SRC / "dpx_regions2.h", SRC / "dpx_binsort.h", SRC / "dpx_refine.h", SRC / "dpx_planefit_fast.h", SRC / "dpx_fit.h", SRC / "dpx_math.h", SRC / "dpx_png.h",
+    return [SRC / "dpx_api.hip", SRC / "dpx_kernels.h", SRC / "dpx_regions.h", SRC / "dpx_regions2.h", SRC / "dpx_regions3.h", SRC / "dpx_binsort.h", SRC / "dpx_refine.h", SRC / "dpx_planefit_fast.h", SRC / "dpx_fit.h", SRC / "dpx_math.h", SRC / "dpx_png.h",
             PKG.parent / "include" / "deplex_amd.h"]
 
 
@@ -42,12 +42,20 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     return OUT
 
 
+def variant_path(name: str) -> Path:
+    return OUT.parent / "variants" / f"{name}.so"
+
+
 def build_variant(name: str, defines=(), force: bool = False) -> Path:
     """An experimental / diagnostic build of the same library under lib/variants/<name>.so (selected with DPX_LIB_PATH):
-    "trace" = -DDPX_TRACE, the wave trace of tools/wave_trace.py."""
+    "trace" = -DDPX_TRACE, the wave trace of tools/wave_trace.py; "diag" = -DDPX_DIAG: the phase-stamp instantiations of the
+    region kernels (dpx_debug_region_phases / dpx_debug_cores_phases), the timing-only plane-fit instantiations
+    (DPX_PF_DIAG), DPX_SKIP (stages left out: results are garbage) and DPX_SYNC_EACH — none of which the product library has."""
     if name == "trace" and not defines:
         defines = ("DPX_TRACE",)
-    out = OUT.parent / "variants" / f"{name}.so"
+    if name == "diag" and not defines:
+        defines = ("DPX_DIAG",)
+    out = variant_path(name)
     if not force and out.exists() and all(s.stat().st_mtime <= out.stat().st_mtime for s in sources()):
         return out
     out.parent.mkdir(parents=True, exist_ok=True)

@@ -118,15 +118,32 @@ class PlaneExtractor {
  *  (ideally page-locked) output at the range's offset.  No exchange between devices. */
 class ShardedExtractor {
  public:
+  /** `slots` batches of `max_batch` frames are in flight per device (dpx_pipeline with host-buffer submissions: every slot's
+   *  stream carries copy in, kernels, copy out).  Set GPU_MAX_HW_QUEUES >= slots per device before HIP initialises. */
   ShardedExtractor(int32_t image_height, int32_t image_width, std::vector<int32_t> const& devices, config::Config config = config::Config(),
-                   int32_t max_batch = 64)
+                   int32_t max_batch = 64, int32_t slots = 3)
       : height_(image_height), width_(image_width), max_batch_(max_batch) {
     if (devices.empty()) throw std::runtime_error("ShardedExtractor needs at least one device");
-    for (int32_t d : devices) shards_.emplace_back(image_height, image_width, config, max_batch, d);
+    const dpx_config c = config.to_c();
+    for (int32_t d : devices) {
+      shards_.emplace_back(image_height, image_width, config, max_batch, d);
+      dpx_pipeline p = nullptr;
+      if (dpx_pipeline_create(&c, image_height, image_width, max_batch, d, slots, 1, &p) != DPX_OK) {
+        for (dpx_pipeline q : pipes_) dpx_pipeline_destroy(q);
+        throw std::runtime_error(dpx_last_error());
+      }
+      pipes_.push_back(p);
+    }
   }
+  ~ShardedExtractor() {
+    for (dpx_pipeline p : pipes_) dpx_pipeline_destroy(p);
+  }
+  ShardedExtractor(ShardedExtractor const&) = delete;
+  ShardedExtractor& operator=(ShardedExtractor const&) = delete;
   static std::pair<int64_t, int64_t> shardRange(int64_t n_frames, int64_t rank, int64_t world) {
     return {n_frames * rank / world, n_frames * (rank + 1) / world};
   }
+  /** depth: batch x H x W uint16 in host memory (page-locked: the copies run asynchronously); labels: batch x H x W int32 */
   void processDepthBatch(uint16_t const* depth, int64_t batch, float fx, float fy, float cx, float cy, int32_t* labels) {
     const size_t n = static_cast<size_t>(height_) * width_;
     const int64_t world = static_cast<int64_t>(shards_.size());
@@ -137,10 +154,15 @@ class ShardedExtractor {
       if (range.second <= range.first) continue;
       threads.emplace_back([&, g, range] {
         try {
-          for (int64_t s = range.first; s < range.second; s += max_batch_) {
-            const int32_t b = static_cast<int32_t>(std::min<int64_t>(max_batch_, range.second - s));
-            shards_[static_cast<size_t>(g)].processDepthBatch(depth + static_cast<size_t>(s) * n, b, fx, fy, cx, cy, labels + static_cast<size_t>(s) * n);
-          }
+          dpx_pipeline p = pipes_[static_cast<size_t>(g)];
+          int64_t s = range.first;
+          for (; s + max_batch_ <= range.second; s += max_batch_)  // whole chunks stream through the shard's pipeline
+            if (dpx_pipeline_submit_depth_host(p, depth + static_cast<size_t>(s) * n, max_batch_, fx, fy, cx, cy, labels + static_cast<size_t>(s) * n) != DPX_OK)
+              throw std::runtime_error(dpx_last_error());
+          if (s < range.second)  // the remainder: one blocking call
+            shards_[static_cast<size_t>(g)].processDepthBatch(depth + static_cast<size_t>(s) * n, static_cast<int32_t>(range.second - s), fx, fy, cx, cy,
+                                                             labels + static_cast<size_t>(s) * n);
+          if (dpx_pipeline_sync(p) != DPX_OK) throw std::runtime_error(dpx_last_error());
         } catch (std::exception const& e) {
           errors[static_cast<size_t>(g)] = e.what();
         }
@@ -155,6 +177,7 @@ class ShardedExtractor {
  private:
   int32_t height_, width_, max_batch_;
   std::vector<PlaneExtractor> shards_;
+  std::vector<dpx_pipeline> pipes_;
 };
 
 /** A stream of HOST batches through one GPU (not in the reference): `slots` batches are in flight, each on its own

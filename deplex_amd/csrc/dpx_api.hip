@@ -22,6 +22,18 @@
 #include "dpx_refine.h"
 #include "dpx_png.h"
 
+// Diagnostics that can return garbage (DPX_SKIP: stages left out for timing), run timing-only instantiations (DPX_PF_DIAG) or
+// stamped / synchronising forms of the region kernels (dpx_debug_region_phases, DPX_SYNC_EACH) exist only in the -DDPX_DIAG
+// build (deplex_amd/build.py build_variant("diag") -> lib/variants/diag.so, selected with DPX_LIB_PATH); the product library
+// has neither the switches nor the code.
+#ifdef DPX_DIAG
+#define DPX_IF_DIAG(...) __VA_ARGS__
+#define DPX_DIAG_GETENV(name) std::getenv(name)
+#else
+#define DPX_IF_DIAG(...)
+#define DPX_DIAG_GETENV(name) static_cast<const char*>(nullptr)
+#endif
+
 namespace {
 
 thread_local std::string g_err;
@@ -276,12 +288,19 @@ void launch_planefit_fast(const dpx::Params& prm, const dpx::PfGroup& grp, dpx_c
   static const int wpb = std::getenv("DPX_PF_BLOCK_WAVES") ? std::max(1, std::min(8, std::atoi(std::getenv("DPX_PF_BLOCK_WAVES")))) : kPfBlockWaves;
   const unsigned blocks = static_cast<unsigned>((waves + wpb - 1) / wpb);
   const dim3 bd(64u * wpb);
-  static const int diag = std::getenv("DPX_PF_DIAG") ? std::atoi(std::getenv("DPX_PF_DIAG")) : 0;
-  if (P == 10 && diag == 1)
+#ifdef DPX_DIAG
+  static const int diag = std::getenv("DPX_PF_DIAG") ? std::atoi(std::getenv("DPX_PF_DIAG")) : 0;  // timing-only instantiations
+  if (P == 10 && diag == 1) {
     hipLaunchKernelGGL((dpx::k_planefit_depth<10, true, 1>), dim3(blocks), bd, 0, s, prm, grp, d_cells);
-  else if (P == 10 && diag == 2)
+    return;
+  }
+  if (P == 10 && diag == 2) {
     hipLaunchKernelGGL((dpx::k_planefit_depth<10, true, 2>), dim3(blocks), bd, 0, s, prm, grp, d_cells);
-  else if (fastdiv)
+    return;
+  }
+#endif
+  if (false) {
+  } else if (fastdiv)
     hipLaunchKernelGGL((dpx::k_planefit_depth<P, true>), dim3(blocks), bd, 0, s, prm, grp, d_cells);
   else
     hipLaunchKernelGGL((dpx::k_planefit_depth<P, false>), dim3(blocks), bd, 0, s, prm, grp, d_cells);
@@ -436,7 +455,7 @@ int stage_fit(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool de
   const bool prof = h->profiling;
   hipEvent_t* ev = h->ev[h->prof_calls % dpx_handle_s::kProfSlots];
   // DPX_SKIP=<letters f r l>: timing-only diagnostics that leave out a stage (results are garbage); tools/stage_cost.sh
-  static const char* skip = std::getenv("DPX_SKIP");
+  static const char* skip = DPX_DIAG_GETENV("DPX_SKIP");
   // 'F': the plane fit runs only the first two times on a handle, so that the later (timed) calls of the other stages
   // still work on real cell records
   const bool skip_f = allow_skip && skip && (std::strchr(skip, 'f') || (std::strchr(skip, 'F') && h->fit_calls >= 2));
@@ -503,7 +522,7 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   prm.batch = batch;
   const bool prof = h->profiling;
   hipEvent_t* ev = h->ev[h->prof_calls % dpx_handle_s::kProfSlots];
-  static const char* skip = std::getenv("DPX_SKIP");
+  static const char* skip = DPX_DIAG_GETENV("DPX_SKIP");
   const bool skip_r = skip && std::strchr(skip, 'r'), skip_l = skip && std::strchr(skip, 'l');
   // ---- cell graph (only when the region kernel does not compute it itself) + region growing
   if (prof) DPX_HIP(hipEventRecord(ev[2], s));
@@ -548,7 +567,7 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   rx.frames_per_out = per_sub;
   for (int j = 0; j < dpx::kMaxGroup; ++j) rx.labels_out[j] = (fuse_labels && j < nsub) ? subs[j].d_labels : nullptr;
   // diagnostic (DPX_SYNC_EACH=1): wait for every launch of the core path and name it on stderr — finds a launch that never ends
-  static const bool sync_each = std::getenv("DPX_SYNC_EACH") != nullptr;
+  static const bool sync_each = DPX_DIAG_GETENV("DPX_SYNC_EACH") != nullptr;
   auto CHK = [&](const char* name) {
     if (sync_each) {
       const hipError_t e1 = hipStreamSynchronize(s);
@@ -570,17 +589,18 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
       ob.hdr = reinterpret_cast<const int*>(h->d_lds_img); ob.queue = h->d_gqueue; ob.task = h->d_order_task; ob.pcap = h->pcap;
       ob.dbg = sb.dbg;
       const int per_frame = std::max(1, std::min(16, 512 / std::max(1, batch)));
-      if (h->d_dbg) (void)hipMemsetAsync(h->d_dbg + (static_cast<size_t>(h->max_batch)) * dpx::kDbgSlots, 0, static_cast<size_t>(batch) * dpx::kDbgSlots * 8, s);
-      if (h->d_dbg) hipLaunchKernelGGL(dpx::k_regsim<true>, dim3(batch), dim3(64), h->lds3_sim, s, prm, sb);
-      else hipLaunchKernelGGL(dpx::k_regsim<false>, dim3(batch), dim3(64), h->lds3_sim, s, prm, sb);
+      DPX_IF_DIAG(if (h->d_dbg) (void)hipMemsetAsync(h->d_dbg + (static_cast<size_t>(h->max_batch)) * dpx::kDbgSlots, 0, static_cast<size_t>(batch) * dpx::kDbgSlots * 8, s);
+                  if (h->d_dbg) hipLaunchKernelGGL(dpx::k_regsim<true>, dim3(batch), dim3(64), h->lds3_sim, s, prm, sb); else)
+      hipLaunchKernelGGL(dpx::k_regsim<false>, dim3(batch), dim3(64), h->lds3_sim, s, prm, sb);
       CHK("k_regsim");
       hipLaunchKernelGGL(dpx::k_cellgrow, cell_grid, dim3(256), 0, s, prm, core_bufs(h));
       CHK("k_cellgrow");
       const int per_frame_huge = std::max(1, std::min(4, 128 / std::max(1, batch)));
-      if (h->d_dbg) {
+      DPX_IF_DIAG(if (h->d_dbg) {
         hipLaunchKernelGGL((dpx::k_order<true, true>), dim3(per_frame_huge, batch), dim3(dpx::kOrderWaves * 64), h->lds3_order, s, prm, ob);
         hipLaunchKernelGGL((dpx::k_order<true, false>), dim3(per_frame, batch), dim3(dpx::kOrderWaves * 64), 0, s, prm, ob);
-      } else {
+      } else)
+      {
         hipLaunchKernelGGL((dpx::k_order<false, true>), dim3(per_frame_huge, batch), dim3(dpx::kOrderWaves * 64), h->lds3_order, s, prm, ob);
         hipLaunchKernelGGL((dpx::k_order<false, false>), dim3(per_frame, batch), dim3(dpx::kOrderWaves * 64), 0, s, prm, ob);
       }
@@ -596,8 +616,8 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
       CHK("k_seg_accum");
       hipLaunchKernelGGL(dpx::k_seg_fit, dim3(static_cast<unsigned>((h->pcap + 255) / 256), static_cast<unsigned>(batch)), dim3(256), 0, s, prm, tb);
       CHK("k_seg_fit");
-      if (h->d_dbg) hipLaunchKernelGGL((dpx::k_regions2<0, true, 5>), dim3(batch), dim3(dpx::kTail5RT), h->lds2_p3, s, prm, rb, rx);
-      else hipLaunchKernelGGL((dpx::k_regions2<0, false, 5>), dim3(batch), dim3(dpx::kTail5RT), h->lds2_p3, s, prm, rb, rx);
+      DPX_IF_DIAG(if (h->d_dbg) hipLaunchKernelGGL((dpx::k_regions2<0, true, 5>), dim3(batch), dim3(dpx::kTail5RT), h->lds2_p3, s, prm, rb, rx); else)
+      hipLaunchKernelGGL((dpx::k_regions2<0, false, 5>), dim3(batch), dim3(dpx::kTail5RT), h->lds2_p3, s, prm, rb, rx);
       CHK("k_regions2<0, ., 5>");
     }
   } else if (h->regions_tier == 0 && h->tier0_split && !h->d_dbg) {
@@ -608,12 +628,15 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
     hipLaunchKernelGGL((dpx::k_regions2<1, false, 1>), dim3(batch), dim3(dpx::kRT), h->lds2_p1, s, prm, rb, rx);
     hipLaunchKernelGGL((dpx::k_regions2<1, false, 2>), dim3(batch), dim3(64), h->lds2_p2, s, prm, rb, rx);
     hipLaunchKernelGGL((dpx::k_regions2<1, false, 3>), dim3(batch), dim3(dpx::kTailRT), h->lds2_p3, s, prm, rb, rx);
-  } else if (h->regions_tier == 2 && h->d_dbg)
+  }
+#ifdef DPX_DIAG
+  else if (h->regions_tier == 2 && h->d_dbg)
     hipLaunchKernelGGL((dpx::k_regions2<2, true, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
   else if (h->regions_tier == 1 && h->d_dbg)
     hipLaunchKernelGGL((dpx::k_regions2<1, true, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
   else if (h->regions_tier == 0 && h->d_dbg)
     hipLaunchKernelGGL((dpx::k_regions2<0, true, 0>), dim3(batch), dim3(dpx::kRT), h->lds2_bytes, s, prm, rb, rx);
+#endif
   else if (h->regions_tier == 2 && h->regions_split) {
     const bool skip_p2 = skip && std::strchr(skip, '2'), skip_p3 = skip_p2 || (skip && std::strchr(skip, '3'));
     if (h->opt_prep_grow_fused && !skip_p2) {
@@ -1181,13 +1204,13 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
       rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
   }
   if (rc == DPX_OK && h->cores && h->lds3_order + 8192 > 48 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_order<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds3_order)) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_order<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds3_order)) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_order<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds3_order)) != hipSuccess
+        DPX_IF_DIAG(|| hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_order<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds3_order)) != hipSuccess))
       rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
   }
   if (rc == DPX_OK && h->cores && h->lds3_sim > 48 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regsim<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds3_sim)) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regsim<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds3_sim)) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regsim<false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds3_sim)) != hipSuccess
+        DPX_IF_DIAG(|| hipFuncSetAttribute(reinterpret_cast<const void*>(dpx::k_regsim<true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h->lds3_sim)) != hipSuccess))
       rc = fail(DPX_ERR_HIP, "hipFuncSetAttribute failed");
   }
   if (rc == DPX_OK && (h->regions_tier == 2 || h->regions_tier == 1 || h->tier0_split || h->cores)) {
@@ -1556,6 +1579,9 @@ int64_t dpx_debug_read_cores(dpx_handle h, int32_t which, int32_t frame, void* o
 
 int dpx_debug_cores_phases(dpx_handle h, int32_t frame, uint64_t* out32) {
   if (!h || !out32) return fail(DPX_ERR_ARG, "null argument");
+#ifndef DPX_DIAG
+  return fail(DPX_ERR_ARG, "this build has no phase stamps: use the -DDPX_DIAG variant (deplex_amd.build.build_variant('diag'), DPX_LIB_PATH)");
+#endif
   if (!h->d_dbg || !h->cores || frame < 0 || frame >= h->max_batch) return fail(DPX_ERR_ARG, "diagnostics not enabled, not the core path, or bad frame");
   DPX_HIP(hipSetDevice(h->device));
   DPX_HIP(hipStreamSynchronize(h->last_stream));
@@ -1565,6 +1591,10 @@ int dpx_debug_cores_phases(dpx_handle h, int32_t frame, uint64_t* out32) {
 
 int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_t* out32) {
   if (!h) return fail(DPX_ERR_ARG, "null handle");
+#ifndef DPX_DIAG
+  if (enable || out32) return fail(DPX_ERR_ARG, "this build has no phase stamps: use the -DDPX_DIAG variant (deplex_amd.build.build_variant('diag'), DPX_LIB_PATH)");
+  return DPX_OK;
+#else
   DPX_HIP(hipSetDevice(h->device));
   if (enable && !h->d_dbg) {
     // (two blocks of kDbgSlots words per frame: the k_regions2 stamps, then those of the core path's sequence / order launches)
@@ -1590,6 +1620,7 @@ int dpx_debug_region_phases(dpx_handle h, int32_t enable, int32_t frame, uint64_
     h->d_dbg = nullptr;
   }
   return DPX_OK;
+#endif
 }
 
 int dpx_debug_trace(int32_t device, uint64_t* d_buf, uint32_t cap_per_slot, uint32_t* counts) {
@@ -1675,6 +1706,18 @@ int dpx_pipeline_create(const dpx_config* cfg, int32_t image_height, int32_t ima
   *out = nullptr;
   if (group < 1) group = 1;
   if (group > dpx::kMaxGroup) group = dpx::kMaxGroup;
+  {
+    // HIP maps streams to GPU_MAX_HW_QUEUES hardware queues (default 4), read when the runtime initialises: slots beyond
+    // that share a queue and a launch waiting there holds up its neighbour.  Said once.
+    static bool warned = false;
+    const char* q = std::getenv("GPU_MAX_HW_QUEUES");
+    const int queues = q ? std::atoi(q) : 4;
+    if (!warned && slots > queues) {
+      warned = true;
+      std::fprintf(stderr, "[deplex_amd] a pipeline of %d slots with GPU_MAX_HW_QUEUES=%d: set GPU_MAX_HW_QUEUES >= slots (per device) "
+                           "before HIP initialises, or the slots' streams share hardware queues\n", slots, queues);
+    }
+  }
   dpx_pipeline p = new dpx_pipeline_s();
   p->device = device;
   p->group = group;

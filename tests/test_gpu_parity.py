@@ -417,26 +417,36 @@ def test_sweep_round_paths_are_exercised(D, oracle):
     """The two bounded structures of a sweep round — the 64-entry staging of events gathered from several chunks of the
     bin list, and the 64 items (non-seed cells) a round can claim — are hit by a quilt of many tilt directions: the
     diagnostic instantiation counts rounds that gathered and grows given up beyond the 64th item, and the results equal
-    the oracle's all the same (tier 1 and tier 0)."""
-    from deplex_amd import _capi
+    the oracle's all the same (tier 1 and tier 0).  The counters exist only in the -DDPX_DIAG build of the library
+    (lib/variants/diag.so, built by __graft_entry__.build()): a child process loads that one."""
+    import subprocess
+    import sys
+    from deplex_amd import build as B
     depth = np.stack([synth.quilt_depth(960, 1280, seed=11, kmax=3, ntilt=90), synth.quilt_depth(960, 1280, seed=12, kmax=2, ntilt=150, jitter=0.2)])
     intr = synth.intrinsics_for(960, 1280)
+    diag = B.build_variant("diag")
+    child = (
+        "import sys, numpy as np; sys.path.insert(0, 'tests'); import synth, deplex_amd as D; from deplex_amd import _capi\n"
+        "depth = np.stack([synth.quilt_depth(960, 1280, seed=11, kmax=3, ntilt=90), synth.quilt_depth(960, 1280, seed=12, kmax=2, ntilt=150, jitter=0.2)])\n"
+        "ex = D.PlaneExtractor(960, 1280, max_batch=2)\n"
+        "_capi.check(_capi.lib().dpx_debug_region_phases(ex._h, 1, 0, None))\n"
+        "lab = ex.process_depth_batch(depth, *synth.intrinsics_for(960, 1280))\n"
+        "g = o = 0\n"
+        "for f in range(2):\n"
+        "    out = np.zeros(32, dtype=np.uint64); _capi.check(_capi.lib().dpx_debug_region_phases(ex._h, 1, f, out.ctypes.data)); g += int(out[28]); o += int(out[29])\n"
+        "import hashlib; print('RESULT', g, o, hashlib.sha256(lab.tobytes()).hexdigest())\n")
     for env in (None, "DPX_REGIONS_GSTATE"):
         if env:
             os.environ[env] = "1"
         try:
-            full_compare(D, oracle, depth, intr, oracle.default_config())
-            ex = D.PlaneExtractor(960, 1280, max_batch=2)
-            _capi.check(_capi.lib().dpx_debug_region_phases(ex._h, 1, 0, None))
-            ex.process_depth_batch(depth, *intr)
-            gathered = over = 0
-            for f in range(2):
-                out = np.zeros(32, dtype=np.uint64)
-                _capi.check(_capi.lib().dpx_debug_region_phases(ex._h, 1, f, out.ctypes.data))
-                gathered += int(out[28])
-                over += int(out[29])
-            assert gathered > 0, "no round took events from several chunks"
-            assert over > 0, "no round ran into the item limit"
+            labels = full_compare(D, oracle, depth, intr, oracle.default_config())
+            cenv = dict(os.environ, DPX_LIB_PATH=str(diag))
+            r = subprocess.run([sys.executable, "-c", child], cwd=str(Path(__file__).resolve().parents[1]), env=cenv, capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-2000:]
+            _, gathered, over, digest = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][0].split()
+            assert int(gathered) > 0, "no round took events from several chunks"
+            assert int(over) > 0, "no round ran into the item limit"
+            assert digest == hashlib.sha256(labels.tobytes()).hexdigest(), "the diagnostic build's labels differ from the product build's"
         finally:
             if env:
                 del os.environ[env]
@@ -866,8 +876,9 @@ def test_cell_level_output_matches_pixel_labels(D, oracle):
 
 
 def test_sharded_extractor_two_shards_on_one_gpu(D, oracle):
-    """deplex_amd.ShardedExtractor with devices=[0, 0] (two extractors, two host threads, one GPU): ragged shards, chunks
-    of max_batch, results in disjoint slices of one page-locked buffer — label maps and cell-level output vs the oracle."""
+    """deplex_amd.ShardedExtractor with devices=[0, 0] (two shards, two host threads, one GPU; every shard streams whole
+    chunks of max_batch through its own three-slot pipeline with host-buffer submissions and takes the remainder through its
+    extractor): ragged shards, results in disjoint slices of one page-locked buffer — label maps and cell-level output vs the oracle."""
     depth = synth.synth_batch(21, 240, 320, seed0=300)
     intr = synth.intrinsics_for(240, 320)
     oracle.set_math("devmath")
@@ -881,6 +892,10 @@ def test_sharded_extractor_two_shards_on_one_gpu(D, oracle):
     assert np.array_equal(sh.process_depth_batch(depth[:1], *intr), ref[:1])  # fewer frames than devices
     cl, planes = sh.process_depth_batch_cells(depth, *intr)
     assert np.array_equal(sh.extractors[0].expand_cell_labels(cl), ref)
+    cl2, none = sh.process_depth_batch_cells(depth, *intr, planes=False)  # streamed through the shards' pipelines
+    assert none is None and np.array_equal(cl2, cl)
+    pageable = np.empty((21, 240 * 320), np.int32)  # (pageable output: the copies are then synchronous, the results the same)
+    assert np.array_equal(sh.process_depth_batch(depth, *intr, out=pageable), ref)
     single = D.PlaneExtractor(240, 320, max_batch=21)
     single.process_depth_batch(depth, *intr)
     for k in (0, 9, 10, 20):

@@ -1,4 +1,6 @@
 """Diagnostic: shader-clock cycles of the core-based region path's launches per frame.  usage: cores_phases.py H W batch [quilt]"""
+import os as _os
+_os.environ.setdefault("DPX_LIB_PATH", str(__import__("pathlib").Path(__file__).resolve().parents[1] / "deplex_amd" / "lib" / "variants" / "diag.so"))  # the -DDPX_DIAG build
 import sys
 from pathlib import Path
 import numpy as np

@@ -1,6 +1,8 @@
 """Diagnostic: can the plane-fit launch (VALU-bound, no LDS) overlap with the region + label kernels of OTHER groups when
 nothing orders them?  Runs the pipeline without its own plane fits (DPX_SKIP=F: real cell records from the first calls)
 while an independent stream issues plane-fit group launches back to back, and compares with each running alone."""
+import os as _os
+_os.environ.setdefault("DPX_LIB_PATH", str(__import__("pathlib").Path(__file__).resolve().parents[1] / "deplex_amd" / "lib" / "variants" / "diag.so"))  # the -DDPX_DIAG build
 import os, sys, threading, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 os.environ["DPX_SKIP"] = sys.argv[1] if len(sys.argv) > 1 else "F"

@@ -1,4 +1,6 @@
 """Timing-only breakdown of the plane-fit kernel (diagnostic instantiations; outputs are garbage for DIAG != 0)."""
+import os as _os
+_os.environ.setdefault("DPX_LIB_PATH", str(__import__("pathlib").Path(__file__).resolve().parents[1] / "deplex_amd" / "lib" / "variants" / "diag.so"))  # the -DDPX_DIAG build
 import os, sys, subprocess
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]

@@ -1,5 +1,7 @@
 """Diagnostic: per-phase shader-clock cycles of the region-growing kernel (s_memtime: the shader clock, 2.4 GHz under load on MI355X; s_memrealtime is the 100 MHz one).
 usage: region_phases.py [H W batch]   (default: the bench workload, 64 TUM-like 640x480 frames)"""
+import os as _os
+_os.environ.setdefault("DPX_LIB_PATH", str(__import__("pathlib").Path(__file__).resolve().parents[1] / "deplex_amd" / "lib" / "variants" / "diag.so"))  # the -DDPX_DIAG build
 import sys
 from pathlib import Path
 import numpy as np
