@@ -20,14 +20,17 @@ def table(path):
 F, Wt = table(ff), table(wf)
 b = json.loads(open(bj).read().strip().splitlines()[-1])
 frames = b["config"]["batch_per_gpu"] * (b["steps"] + b["warmup"])
+# the plane-fit kernel also runs the bench's stand-alone series (--roofline-iters 1: three warm-up launches + one timed launch of a whole group)
+pf_frames = frames + 4 * b["config"]["batch_per_gpu"] * b["config"]["batches_per_launch"]
 print(open(ff).read().rstrip()); print(open(wf).read().rstrip())
 own = lambda k: k.startswith("dpx::") and "verify_fastdiv" not in k
-fetch = sum(n * v for k, (n, v) in F.items() if own(k))
-write = sum(n * v for k, (n, v) in Wt.items() if own(k))
+scale = lambda k: frames / pf_frames if "planefit" in k else 1.0
+fetch = sum(n * v * scale(k) for k, (n, v) in F.items() if own(k))
+write = sum(n * v * scale(k) for k, (n, v) in Wt.items() if own(k))
 m = re.search(r"\((\d+)x(\d+)\)", b["metric"])
 N = int(m.group(1)) * int(m.group(2))
 per_frame = (2 * fetch + write) * 1024 / frames
-per_kernel = {k: round((2 * F.get(k, (0, 0))[0] * F.get(k, (0, 0))[1] + Wt.get(k, (0, 0))[0] * Wt.get(k, (0, 0))[1]) * 1024 / frames) for k in sorted(set(F) | set(Wt)) if own(k)}
+per_kernel = {k: round((2 * F.get(k, (0, 0))[0] * F.get(k, (0, 0))[1] + Wt.get(k, (0, 0))[0] * Wt.get(k, (0, 0))[1]) * scale(k) * 1024 / frames) for k in sorted(set(F) | set(Wt)) if own(k)}
 print(json.dumps({"workload": wl, "frames_counted": frames, "hbm_bytes_per_frame": int(round(per_frame)), "algorithmic_bytes_per_frame": N * 6,
                   "ratio": round(per_frame / (N * 6), 3), "bytes_per_frame_by_kernel": per_kernel,
                   "correction": "2 x FETCH_SIZE + WRITE_SIZE (KiB; gfx950 counts 128-B read requests at 64 B, MI355X_MICROARCH.md HBM section), summed over every "

@@ -12,7 +12,7 @@ for wl in ${@:-tum_stream synth1280 synth4k}; do
   case $wl in tum_stream) extra="--steps 256 --warmup 32";; *) extra="";; esac
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf $out/$c
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -o pmc -- python3 bench.py --workload $wl $extra --no-cpu-baseline --no-cloud-roofline --no-sustained --no-end-to-end --parity-frames 0 > $out/bench_$c.json 2>$out/$c.err
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -o pmc -- python3 bench.py --workload $wl $extra --no-cpu-baseline --no-cloud-roofline --no-sustained --no-end-to-end --parity-frames 0 --roofline-iters 1 > $out/bench_$c.json 2>$out/$c.err
     python3 tools/pmc_table.py $(ls $out/$c/*counter_collection.csv $out/$c/*/*counter_collection.csv 2>/dev/null | head -1) > $out/$c.txt
     rm -rf $out/$c
   done
