@@ -597,11 +597,11 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
       CHK("k_cellgrow");
       const int per_frame_huge = std::max(1, std::min(4, 128 / std::max(1, batch)));
       DPX_IF_DIAG(if (h->d_dbg) {
-        hipLaunchKernelGGL((dpx::k_order<true, true>), dim3(per_frame_huge, batch), dim3(dpx::kOrderWaves * 64), h->lds3_order, s, prm, ob);
+        hipLaunchKernelGGL((dpx::k_order<true, true>), dim3(per_frame_huge, batch), dim3(dpx::kHugeWaves * 64), h->lds3_order, s, prm, ob);
         hipLaunchKernelGGL((dpx::k_order<true, false>), dim3(per_frame, batch), dim3(dpx::kOrderWaves * 64), 0, s, prm, ob);
       } else)
       {
-        hipLaunchKernelGGL((dpx::k_order<false, true>), dim3(per_frame_huge, batch), dim3(dpx::kOrderWaves * 64), h->lds3_order, s, prm, ob);
+        hipLaunchKernelGGL((dpx::k_order<false, true>), dim3(per_frame_huge, batch), dim3(dpx::kHugeWaves * 64), h->lds3_order, s, prm, ob);
         hipLaunchKernelGGL((dpx::k_order<false, false>), dim3(per_frame, batch), dim3(dpx::kOrderWaves * 64), 0, s, prm, ob);
       }
       CHK("k_order");

@@ -1185,21 +1185,25 @@ constexpr int kOrderClaim = 256;  // claim-table slots per wave
 // its target that sits earlier in the batch — with the batch's (cell -> slot) map in a small LDS hash table instead of a
 // queue-position array: no global memory inside a step.
 constexpr int kHugeRingBits = 12, kHugeRing = 1 << kHugeRingBits;
-constexpr int kHugeHash = 1024;  // slots of the batch map (a batch holds up to 16 * kOrderWaves cells)
-__host__ __device__ inline size_t order_lds_bytes(int C) { return (static_cast<size_t>(C) + 15u) / 16u * 16u + 4u * kHugeRing + 4u * kHugeHash + 64u; }
+constexpr int kHugeHash = 2048;  // slots of the batch map (a batch holds up to 16 * kHugeWaves = 256 cells)
+__host__ __device__ inline size_t order_lds_bytes(int C) { return (static_cast<size_t>(C) + 15u) / 16u * 16u + 4u * kHugeRing + 4u * kHugeHash + 128u; }  // (+ control words: task, per-wave counts)
 
 // HUGE = the launch that orders the huge grows (dynamic LDS: order_lds_bytes); the other launch takes the waves' tasks
+constexpr int kHugeWaves = 16;  // waves of the launch that orders huge grows: 256 queue slots per step
 template <bool DBG, bool HUGE>
-__global__ __launch_bounds__(kOrderWaves * 64) void k_order(Params prm, OrderBufs ob) {
+__global__ __launch_bounds__((HUGE ? kHugeWaves : kOrderWaves) * 64) void k_order(Params prm, OrderBufs ob) {
+  constexpr int kOrderWaves = HUGE ? kHugeWaves : dpx::kOrderWaves;  // (this launch's)
   const unsigned long long t_start = DBG ? static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) : 0ull;
   const int frame = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int C = prm.C, nh = prm.nh;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  __shared__ uint32_t s_claim[kOrderWaves][kOrderClaim];
-  uint32_t* ctab = s_claim[wid];
-  for (int i = lane; i < kOrderClaim; i += 64) ctab[i] = 0xFFFFFFFFu;
-  wave_sync();
+  __shared__ uint32_t s_claim[HUGE ? 1 : kOrderWaves][kOrderClaim];
+  uint32_t* ctab = s_claim[HUGE ? 0 : wid];
+  if (!HUGE) {
+    for (int i = lane; i < kOrderClaim; i += 64) ctab[i] = 0xFFFFFFFFu;
+    wave_sync();
+  }
   const size_t fo = static_cast<size_t>(frame) * C;
   uint32_t* cellq = ob.cellq + fo;
   uint32_t* queue = ob.queue + fo;
@@ -1253,7 +1257,7 @@ __global__ __launch_bounds__(kOrderWaves * 64) void k_order(Params prm, OrderBuf
                                 : static_cast<int>(__hip_atomic_load(queue + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         uint32_t myh = 0xFFFFFFFFu;
         if (active && dir == 0) {  // the batch's cells into the map: cell << 8 | slot
-          uint32_t h = (static_cast<uint32_t>(u) * 2654435761u) >> 22;
+          uint32_t h = (static_cast<uint32_t>(u) * 2654435761u) >> 21;
           const uint32_t key = (static_cast<uint32_t>(u) << 8) | static_cast<uint32_t>(gsl);
           while (atomicCAS(&bmap[h], 0xFFFFFFFFu, key) != 0xFFFFFFFFu) h = (h + 1u) & (kHugeHash - 1u);
           myh = h;
@@ -1272,7 +1276,7 @@ __global__ __launch_bounds__(kOrderWaves * 64) void k_order(Params prm, OrderBuf
           for (int e = 0; e < 4; ++e)
             if (win && ((others >> e) & 1u)) {
               const int w = v + (e == 0 ? -nh : (e == 1 ? nh : (e == 2 ? -1 : 1)));
-              uint32_t h = (static_cast<uint32_t>(w) * 2654435761u) >> 22;
+              uint32_t h = (static_cast<uint32_t>(w) * 2654435761u) >> 21;
               for (;;) {
                 const uint32_t k = bmap[h];
                 if (k == 0xFFFFFFFFu) break;
