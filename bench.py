@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="frames per step (default 64; --workload synth1280/synth640/synth4k: the BASELINE batch)")
     ap.add_argument("--unique", type=int, default=-1, help="distinct frames per input batch, tiled to --batch (synthetic workloads)")
     # Pipeline shape.  0 = the one default: 4 slots x groups of 8 — one hardware queue per compute pipe, measured 1.65-1.70 M
-    # frames/s against 1.55-1.60 M with 16 slots and 1.52-1.55 M with 5 or 6 (DESIGN.md section 5); the large-frame
+    # frames/s against 1.55-1.60 M with 16 slots and 1.52-1.55 M with 5 or 6 (DESIGN.md section 6); the large-frame
     # workloads have their own (BIG_WORKLOADS).
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DPX_BENCH_STREAMS", 0)), help="groups in flight (pipeline slots); 0 = auto")
     ap.add_argument("--group", type=int, default=int(os.environ.get("DPX_BENCH_GROUP", 0)), help="submissions per launch sequence (1..32); 0 = auto")
@@ -180,7 +180,7 @@ def main():
     import deplex_amd as D
 
     # ONE default shape, whatever the run length: 4 slots x groups of 8 (one hardware queue per compute pipe of the command
-    # processor; DESIGN.md section 5).  The driver's 20 timed steps are then 2.5 groups — `value` is that short run as it is,
+    # processor; DESIGN.md section 6).  The driver's 20 timed steps are then 2.5 groups — `value` is that short run as it is,
     # `sustained` the same shape over 2000 steps.  (Until round 3 short runs took 16 x 5 because that shape divides 20 steps
     # into whole groups: a number shaped by the protocol, dropped.)
     S = args.streams if args.streams > 0 else (big["streams"] if big else 4)  # groups in flight (pipeline slots), one stream each

@@ -43,7 +43,7 @@ class ShardedExtractor:
     splits the batch into contiguous frame ranges (shard_range), one per entry of `devices`; each range is fed by its own
     host thread, in chunks of `max_batch` frames, through the entry's `Pipeline` of `slots` slots with host-buffer
     submissions (dpx_pipeline_submit_depth_host / _cells_host): every slot's stream carries copy in, kernels, copy out,
-    so one chunk copies in while another computes and a third copies out — the streamed rates of DESIGN.md section 5
+    so one chunk copies in while another computes and a third copies out — the streamed rates of DESIGN.md section 6
     (37 k pixel-label / 90 k cell-label frames/s per device at 640x480) instead of one blocking call at a time (26 k /
     56 k).  A last chunk shorter than `max_batch`, and the cell-level form WITH plane records, go through the entry's plain
     extractor.  Results land in the caller's (ideally page-locked: pinned_empty) output at the range's offset.  There is

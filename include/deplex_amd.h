@@ -134,7 +134,7 @@ int dpx_process_depth_batch(dpx_handle h, const uint16_t* depth, int32_t batch, 
  * back, frame f's first record at the sum of n_planes[0..f); planes_cap = records the buffer can hold; *planes_total
  * (may be NULL) receives the number of records of the batch.  DPX_ERR_CAPACITY (records up to planes_cap copied) if
  * the buffer is too small.  Device-to-host traffic per 640x480 frame: 12 KB + ~3 KB instead of 1.2 MB — the
- * host-pointer entry points are PCIe-bound, so this is ~3x the end-to-end frame rate (DESIGN.md section 5).
+ * host-pointer entry points are PCIe-bound, so this is ~3x the end-to-end frame rate (DESIGN.md section 6).
  * Not defined with ransac_refinement (which edits single pixels): DPX_ERR_ARG. */
 int dpx_process_depth_batch_cells(dpx_handle h, const uint16_t* depth, int32_t batch, float fx, float fy, float cx,
                                   float cy, int32_t* cell_labels, int32_t* n_planes, dpx_plane* planes,
@@ -190,7 +190,7 @@ int dpx_pipeline_submit_depth_cells(dpx_pipeline p, const void* d_depth, int32_t
  * (batch x nv x nh int32) in host memory out.  The frames are copied to a staging buffer of the slot on the slot's
  * stream at submission, the results back after the group's kernels, so the copies of one slot overlap the kernels of
  * the others (three slots keep the PCIe link busy: 90 k frames/s at 640x480 with cell labels, 38 k with pixel maps,
- * DESIGN.md section 5).  Both buffers must stay valid and untouched until dpx_pipeline_sync(); page-locked memory
+ * DESIGN.md section 6).  Both buffers must stay valid and untouched until dpx_pipeline_sync(); page-locked memory
  * (dpx_host_alloc) makes the copies asynchronous, pageable memory works but blocks in the call.  May be mixed with
  * device-buffer submissions. */
 int dpx_pipeline_submit_depth_host(dpx_pipeline p, const uint16_t* h_depth, int32_t batch, float fx, float fy, float cx, float cy,
@@ -207,7 +207,7 @@ int dpx_pipeline_submit_pcd(dpx_pipeline p, const void* d_xyz, int32_t batch, vo
 int dpx_pipeline_sync(dpx_pipeline p);
 /* Launches the submissions recorded so far without waiting for them (a partially filled group is launched as it is and
  * the next submission starts a new group on the next slot).  For callers that want the first results of a stream early,
- * or that want the groups in flight to be at different stages (short runs). */
+ * or that want the groups in flight to be at different stages (docs/EXPERIMENTS.md section 2, short runs). */
 int dpx_pipeline_flush(dpx_pipeline p);
 dpx_handle dpx_pipeline_slot(dpx_pipeline p, int32_t slot);
 
