@@ -17,8 +17,8 @@ LIBS = ["-lz"]  # the PNG reader of the DepthImage path constructor (dpx_png.h) 
 
 
 def sources():
-    return [SRC / "dpx_api.hip", SRC / "dpx_kernels.h", SRC / "dpx_regions.h", SRC / "dpx_regions2.h", SRC / "dpx_regions3.h", SRC / "dpx_binsort.h", SRC / "dpx_refine.h", SRC / "dpx_planefit_fast.h", SRC / "dpx_fit.h", SRC / "dpx_math.h", SRC / "dpx_png.h",
-            PKG.parent / "include" / "deplex_amd.h"]
+    """Everything the library is compiled from: the one translation unit, its headers and the kernel-body fragments."""
+    return [SRC / "dpx_api.hip", *sorted(SRC.glob("*.h")), *sorted(SRC.glob("*.inc")), PKG.parent / "include" / "deplex_amd.h"]
 
 
 def needs_build() -> bool:

@@ -590,8 +590,8 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
       ob.dbg = sb.dbg;
       const int per_frame = std::max(1, std::min(16, 512 / std::max(1, batch)));
       DPX_IF_DIAG(if (h->d_dbg) (void)hipMemsetAsync(h->d_dbg + (static_cast<size_t>(h->max_batch)) * dpx::kDbgSlots, 0, static_cast<size_t>(batch) * dpx::kDbgSlots * 8, s);
-                  if (h->d_dbg) hipLaunchKernelGGL(dpx::k_regsim<true>, dim3(batch), dim3(64), h->lds3_sim, s, prm, sb); else)
-      hipLaunchKernelGGL(dpx::k_regsim<false>, dim3(batch), dim3(64), h->lds3_sim, s, prm, sb);
+                  if (h->d_dbg) hipLaunchKernelGGL(dpx::k_regsim<true>, dim3(batch), dim3(128), h->lds3_sim, s, prm, sb); else)
+      hipLaunchKernelGGL(dpx::k_regsim<false>, dim3(batch), dim3(128), h->lds3_sim, s, prm, sb);
       CHK("k_regsim");
       hipLaunchKernelGGL(dpx::k_cellgrow, cell_grid, dim3(256), 0, s, prm, core_bufs(h));
       CHK("k_cellgrow");

@@ -528,12 +528,17 @@ constexpr uint32_t kCandWide = 0x80000000u;  // cand_grow.w: the grow is ordered
 // (a whole workgroup's work in k_order: they are listed from the END of biglist backwards)
 constexpr int kHdrBig = 4, kHdrHuge = 5;
 constexpr int kHugeMin = 1024;
-constexpr int kWin = 4;  // seed-list entries per bin kept in LDS
+#ifndef DPX_S3_WIN
+#define DPX_S3_WIN 8
+#endif
+constexpr int kWin = DPX_S3_WIN;  // seed-list entries per bin kept in LDS
+constexpr int kScan = 4;         // of which the sequence reads so many at a time
 constexpr int kEdgePre = 4;  // one-way edges of an event's core fetched ahead of its turn
 constexpr int kWideLds = 64; // cores of an irregular grow listed in LDS (more: in global memory)
 
+constexpr int kReqRing = 256;  // refill requests in flight from the sequence's wave to its helper (bins, 16 bits each)
 struct S3Layout {
-  uint32_t hist, cursor, lo, hi, bclaim, nzlist, evb, rrec, rsrc, idata, edata, tk, td, win, cbits, end;
+  uint32_t hist, cursor, lo, hi, bclaim, nzlist, evb, rrec, rsrc, idata, edata, tk, td, req, win, cbits, end;
 };
 __host__ __device__ inline S3Layout s3_layout(int nb, int C) {
   S3Layout L{};
@@ -552,6 +557,7 @@ __host__ __device__ inline S3Layout s3_layout(int nb, int C) {
   L.edata = o; o += 64 * kEdgePre * 16;
   L.tk = o; o += kWideLds * 4;
   L.td = o; o += kWideLds * 8;
+  L.req = o; o += 2u * kReqRing;
   L.win = o; o += 32u * kWin * static_cast<uint32_t>(nb);
   L.cbits = o; o += 4u * static_cast<uint32_t>((C + 31) / 32 + 1);
   L.end = (o + 15u) & ~15u;
@@ -559,7 +565,7 @@ __host__ __device__ inline S3Layout s3_layout(int nb, int C) {
 }
 
 template <bool DBG>
-__global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
+__global__ __launch_bounds__(128) void k_regsim(Params prm, SimBufs sb) {
   WaveTrace trace_(TK_GROW);
 #if DPX_REGIONS_PRIO
   __builtin_amdgcn_s_setprio(DPX_REGIONS_PRIO);
@@ -568,7 +574,7 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
   unsigned long long n_rounds = 0, n_wide = 0, n_irreg = 0, n_refill = 0, n_multi = 0, n_skip = 0, t_setup = 0;
   unsigned long long a_ev = 0, a_seed = 0, a_items = 0, a_walk = 0, a_commit = 0, a_wide = 0, ts0 = 0, ts1 = 0;
 #define S3_STAMP(acc) do { if (DBG) { ts1 = static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()); acc += ts1 - ts0; ts0 = ts1; } } while (0)
-  const int frame = blockIdx.x, lane = threadIdx.x;
+  const int frame = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;  // wave 0: the sequence; wave 1: the windows' helper
   const int C = prm.C;
   const int nb = prm.hist_B * prm.hist_B;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -590,6 +596,7 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
   uint32_t* tkl = reinterpret_cast<uint32_t*>(smem + lay.tk);       // an irregular grow's first cores: IDs taken,
   uint2* tdl = reinterpret_cast<uint2*>(smem + lay.td);             // cores still to expand
   uint32_t* cbits = reinterpret_cast<uint32_t*>(smem + lay.cbits);  // bit (core ID): the core is unassigned
+  uint16_t* req = reinterpret_cast<uint16_t*>(smem + lay.req);      // ring of bins whose window wants entries (hdr[11] head, hdr[12] tail)
 
   const size_t fo = static_cast<size_t>(frame) * C;
   const uint4* lists = sb.lists + 2 * fo;
@@ -598,7 +605,8 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
   uint4* cand_grow = sb.cand_grow + static_cast<size_t>(frame) * sb.pcap;
   uint32_t* biglist = sb.biglist + static_cast<size_t>(frame) * sb.pcap;
 
-  // ---- state: histogram, list bounds, every core alive, non-empty bins
+  // ---- state: histogram, list bounds, every core alive, non-empty bins (wave 0; the helper waits at the barrier below)
+  if (wid == 0) {
   hdr[lane] = 0;
   {
     const uint32_t* bo = sb.bin_off + static_cast<size_t>(frame) * (nb + 1);
@@ -623,7 +631,6 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
     const int npair_total = static_cast<int>(sb.cursor[4 * frame]);
     for (int w = lane; w < (npair_total + 31) / 32 + 1; w += 64) cbits[w] = 0xFFFFFFFFu;
   }
-  const int planar_total = static_cast<int>(sb.cursor[4 * frame + 2]);
   wave_sync();
   {
     int nz = 0;
@@ -637,6 +644,79 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
     if (lane == 0) hdr[5] = nz;
   }
   wave_sync();
+  }
+  __syncthreads();
+  // ---- wave 1, the windows' helper.  Every bin's list has a 4-entry window in LDS; wave 0 reads its seeds there and never
+  // touches the lists in global memory (a cold entry is ~3 000 cycles away).  When it leaves a window with at most one
+  // unread entry it posts the bin in a ring; the helper takes the posted bins, one per lane, loads the next entries into the
+  // window's free slots and then moves the window's end.  Single writer each: wave 0 writes lo[] (entries in front of it are
+  // read or dead) and the ring's head, the helper writes hi[], the slots behind it and the ring's tail; LDS executes a wave's
+  // operations in order, so whoever sees a new end sees the entries.  (A bin posted twice is loaded twice with the same
+  // values.)
+  if (wid == 1) {
+    volatile int* vlo = lo;
+    volatile int* vhi = hi;
+    volatile int* done = hdr + 10;
+    volatile int* vhead = hdr + 11;
+    volatile int* vtail = hdr + 12;
+    int tail = 0;
+    for (int it = 0; it < (1 << 28) && !*done; ++it) {  // (bounded: a helper that stops helping cannot hang the launch)
+      int n = *vhead - tail;
+      if (n <= 0) {
+        __builtin_amdgcn_s_sleep(1);
+        continue;
+      }
+      if (n > 64) n = 64;
+      const unsigned long long hb0 = DBG ? static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) : 0ull;
+      if (lane < n) {
+        const int b = static_cast<volatile uint16_t*>(req)[(tail + lane) & (kReqRing - 1)];
+        const int l = vlo[b], h = vhi[b], e = cursor[b];
+        const int room = kWin - (h - l);
+        const int m = e - h < room ? e - h : room;
+        if (m > 0) {
+          uint4 a[2 * kWin];
+#pragma unroll
+          for (int k = 0; k < kWin; ++k)
+            if (k < m) {
+              a[2 * k] = lists[2 * (h + k)];
+              a[2 * k + 1] = lists[2 * (h + k) + 1];
+            }
+#pragma unroll
+          for (int k = 0; k < kWin; ++k)
+            if (k < m) {
+              const int sl = (b * kWin + ((h + k) & (kWin - 1))) * 2;
+              win[sl] = a[2 * k];
+              win[sl + 1] = a[2 * k + 1];
+            }
+          asm volatile("" ::: "memory");
+          vhi[b] = h + m;
+        }
+      }
+      tail += n;
+      asm volatile("" ::: "memory");
+      if (lane == 0) *vtail = tail;
+      if (DBG && lane == 0) {
+        hdr[13] += 1;
+        hdr[14] += static_cast<int>(static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - hb0);
+        hdr[15] += n;
+      }
+    }
+    return;
+  }
+  int rq_head = 0;
+  // posts the bins of the lanes that ask (the helper's ring never holds more than kReqRing)
+  auto post = [&](bool want, int b) {
+    const unsigned long long m = __ballot(want);
+    if (!m) return;
+    const int cnt = __popcll(m);
+    for (int g = 0; g < (1 << 20) && rq_head + cnt - *static_cast<volatile int*>(hdr + 12) > kReqRing; ++g) __builtin_amdgcn_s_sleep(1);
+    if (want) req[(rq_head + __popcll(m & ((1ull << lane) - 1ull))) & (kReqRing - 1)] = static_cast<uint16_t>(b);
+    rq_head += cnt;
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) *static_cast<volatile int*>(hdr + 11) = rq_head;
+  };
+  const int planar_total = static_cast<int>(sb.cursor[4 * frame + 2]);
   auto alive = [&](uint32_t id) { return ((cbits[id >> 5] >> (id & 31u)) & 1u) != 0u; };
   if (DBG) t_setup = static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - t_start;
 
@@ -648,12 +728,6 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
   for (int q = 0; q < 4; ++q) mybin[q] = (lane + 64 * q < nnz) ? static_cast<int>(nzlist[lane + 64 * q]) : -1;
   const int nsets = (nnz + 63) >> 6;
   int cont_b = -1, cont_level = 0;
-  // a window that an event empties is refilled ahead of time: the loads are issued at the event's commit, their data is
-  // written to the window at the top of the next round — a cold list entry is ~3 000 cycles away, a round of other work
-  int pf_bin = -1, pf_pos = 0, pf_n = 0;
-  uint4 pf[2 * kWin];
-#pragma unroll
-  for (int k = 0; k < 2 * kWin; ++k) pf[k] = make_uint4(0u, 0u, 0u, 0u);
   for (int guard = 0; remaining > 0 && guard <= C; ++guard) {
     if (DBG) { ++n_rounds; ts0 = static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()); }
     // ---- the events of this round: the bins at the histogram's maximum, ascending = lane order (dpx_regions2.h, "sweep
@@ -751,70 +825,56 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
       cont_level = bv;
     }
     const int bs = b >= 0 ? b : 0;
-    if (__ballot(pf_bin >= 0)) {  // last round's prefetches
-      if (pf_bin >= 0) {
-#pragma unroll
-        for (int k = 0; k < kWin; ++k)
-          if (k < pf_n) {
-            const int sl = (pf_bin * kWin + ((pf_pos + k) & (kWin - 1))) * 2;
-            win[sl] = pf[2 * k];
-            win[sl + 1] = pf[2 * k + 1];
-          }
-        hi[pf_bin] = pf_pos + pf_n;
-        pf_bin = -1;
-      }
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-    }
     S3_STAMP(a_ev);
     // ---- seeds: the first live entry of each bin's list (one entry per (core, bin) pair, sorted by the leader's mse, then
     // cell id: plane_extractor.cpp:309-316).  The next few entries of every list sit in an LDS window; a list is read from
     // global memory only when its window runs empty.
     int pos = lo[bs];
-    int whi = hi[bs];
+    int whi = static_cast<volatile int*>(hi)[bs];
     const int lend = cursor[bs];
     uint4 e = make_uint4(0u, 0u, 0u, 0u);
     bool need = part, broken = false;
-    for (;;) {
-      if (need) {
+    for (int spins = 0;; ++spins) {
+      bool ask = false;  // the lane has just read its window to the end
+      if (need && (spins == 0 || whi > pos)) {
         // the window's (up to) four entries and their cores' bits in two LDS round trips; the first live one is the seed
-        uint4 x[kWin];
-        bool ok[kWin];
+        uint4 x[kScan];
+        bool ok[kScan];
 #pragma unroll
-        for (int k = 0; k < kWin; ++k) x[k] = win[(bs * kWin + ((pos + k) & (kWin - 1))) * 2];
+        for (int k = 0; k < kScan; ++k) x[k] = win[(bs * kWin + ((pos + k) & (kWin - 1))) * 2];
 #pragma unroll
-        for (int k = 0; k < kWin; ++k) ok[k] = pos + k < whi && alive(x[k].y);
-        int adv = whi - pos;  // (no live entry: the window is used up)
+        for (int k = 0; k < kScan; ++k) ok[k] = pos + k < whi && alive(x[k].y);
+        int adv = whi - pos < kScan ? whi - pos : kScan;  // (no live entry: these are used up)
 #pragma unroll
-        for (int k = kWin - 1; k >= 0; --k)
+        for (int k = kScan - 1; k >= 0; --k)
           if (ok[k]) {
             e = x[k];
             adv = k;
           }
         need = !(ok[0] || ok[1] || ok[2] || ok[3]);
         pos += adv;
+        ask = need && pos >= whi;
       }
       if (!__ballot(need)) break;
-      if (DBG) ++n_refill;
-      if (need) {  // (pos == whi here)
-        if (pos >= lend) {  // cannot happen (a bin's count is the number of its live cells, every one behind a live leader)
-          broken = true;
-          need = false;
-        } else {
-#pragma unroll
-          for (int k = 0; k < kWin; ++k)
-            if (pos + k < lend) {
-              const int sl = (bs * kWin + ((pos + k) & (kWin - 1))) * 2;
-              win[sl] = lists[2 * (pos + k)];
-              win[sl + 1] = lists[2 * (pos + k) + 1];
-            }
-          whi = pos + kWin < lend ? pos + kWin : lend;
-        }
+      // (pos == whi: every entry the window held is read or dead) — say so, and wait for the helper to move the window's end
+      if (need && (pos >= lend || spins > (1 << 22))) {  // cannot happen (a bin's count is the number of its live cells, every one behind a live leader)
+        broken = true;
+        need = ask = false;
       }
+      if (ask) static_cast<volatile int*>(lo)[bs] = pos;
+      if (DBG && __ballot(ask)) ++n_refill;
       asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
+      post(ask, bs);
+      if (need) whi = static_cast<volatile int*>(hi)[bs];
+      if (!__ballot(need && whi > pos)) __builtin_amdgcn_s_sleep(1);
     }
     if (__ballot(broken)) break;
+    // what the scan stepped over is dead: the helper may already put the next entries there (the seed's own slot stays)
+    if (part) static_cast<volatile int*>(lo)[bs] = pos;
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    post(part && whi < lend && whi - pos < kWin, bs);
     S3_STAMP(a_seed);
     const uint32_t cell = e.x & kCellMask;
     const bool cout_ = (e.x & kCoreOut) != 0u;
@@ -1102,26 +1162,17 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
     S3_STAMP(a_wide);
     if (!pending) break;
     }  // (segments)
-    if (part) {  // list heads and windows of the round's bins
+    if (part) {  // list heads of the round's bins (the helper sees a window running low and refills it)
       const bool used = ((usedmask >> lane) & 1ull) != 0ull;
-      lo[bs] = used ? pos + 1 : pos;
-      hi[bs] = whi;
-      const int left = whi - (used ? pos + 1 : pos);  // entries the window still holds
-      if (left <= 1 && whi < lend) {  // (nearly) empty: fetch its next entries into the free slots
-        pf_bin = bs;
-        pf_pos = whi;
-        pf_n = lend - whi < kWin - left ? lend - whi : kWin - left;
-#pragma unroll
-        for (int k = 0; k < kWin; ++k)
-          if (k < pf_n) {
-            pf[2 * k] = lists[2 * (whi + k)];
-            pf[2 * k + 1] = lists[2 * (whi + k) + 1];
-          }
-      }
+      static_cast<volatile int*>(lo)[bs] = used ? pos + 1 : pos;
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    post(part && whi < lend && ((usedmask >> lane) & 1ull) != 0ull, bs);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
   }
+  if (lane == 0) *static_cast<volatile int*>(hdr + 10) = 1;  // the helper leaves its loop
   // the header the tail launch starts from (k_regions2 PHASE 3 reads hdr[0..3], its segment counter hdr[40] must be 0)
   int* ho = sb.hdr_out + static_cast<size_t>(frame) * 48;
   if (lane < 48) {
@@ -1139,7 +1190,7 @@ __global__ __launch_bounds__(64) void k_regsim(Params prm, SimBufs sb) {
     d[0] = t_setup;
     d[1] = static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - t_start;
     d[11] = n_rounds; d[13] = static_cast<unsigned long long>(ngrow); d[14] = static_cast<unsigned long long>(ncand);
-    d[15] = static_cast<unsigned long long>(tail); d[19] = n_refill; d[21] = n_wide; d[22] = n_skip; d[23] = n_irreg; d[28] = n_multi;
+    d[15] = static_cast<unsigned long long>(tail); d[19] = n_refill; d[24] = static_cast<unsigned long long>(hdr[13]); d[25] = static_cast<unsigned long long>(static_cast<uint32_t>(hdr[14])); d[26] = static_cast<unsigned long long>(hdr[15]); d[21] = n_wide; d[22] = n_skip; d[23] = n_irreg; d[28] = n_multi;
     d[3] = a_ev; d[4] = a_seed; d[5] = a_items; d[6] = a_walk; d[7] = a_commit; d[8] = a_wide;
     d[29] = static_cast<unsigned long long>(sb.cursor[4 * frame]); d[30] = static_cast<unsigned long long>(nbig) | (static_cast<unsigned long long>(nhuge) << 32);
   }

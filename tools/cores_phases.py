@@ -24,5 +24,5 @@ for f in range(B):
     _capi.check(_capi.lib().dpx_debug_region_phases(ex._h, 1, f, a.ctypes.data))
     _capi.check(_capi.lib().dpx_debug_cores_phases(ex._h, f, b.ctypes.data))
     a = [int(v) for v in a]; b = [int(v) for v in b]
-    print(f"frame {f}: sequence={b[1]} (setup {b[0]}) [events {b[3]} seeds {b[4]} items+claims {b[5]} walk {b[6]} commit {b[7]} wide {b[8]}] order(max wave)={b[2]} rounds={b[11]} grows={b[13]} cands={b[14]} (wave-ordered {b[30] & 0xFFFFFFFF}, workgroup-ordered {b[30] >> 32}) activations={b[15]} pairs={b[29]} refills={b[19]} wide={b[21]} skipped={b[22]} irregular={b[23]} multi-rounds={b[28]} | tail: "
+    print(f"frame {f}: sequence={b[1]} (setup {b[0]}) [events {b[3]} seeds {b[4]} items+claims {b[5]} walk {b[6]} commit {b[7]} wide {b[8]}] order(max wave)={b[2]} rounds={b[11]} grows={b[13]} cands={b[14]} (wave-ordered {b[30] & 0xFFFFFFFF}, workgroup-ordered {b[30] >> 32}) activations={b[15]} pairs={b[29]} window waits={b[19]} (helper: {b[24]} batches, {b[26]} requests, {b[25]} cycles) wide={b[21]} skipped={b[22]} irregular={b[23]} multi-rounds={b[28]} | tail: "
           + ", ".join(f"{n}={v}" for n, v in zip(tn, a[:8])) + f", merge walk={a[31]}", "stats", ex.frame_stats(f))

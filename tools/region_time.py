@@ -7,11 +7,11 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np, torch
 import deplex_amd as D, synth
-CFG = {"4k": (2160, 3840, 8, 4), "1280": (960, 1280, 256, 8), "640": (480, 640, 512, 16)}
+CFG = {"4k": (2160, 3840, 8, 4), "4k64": (2160, 3840, 64, 4), "4k64noisy": (2160, 3840, 64, 1, 0), "4k64clean": (2160, 3840, 64, 1, 3), "1280": (960, 1280, 256, 8), "640": (480, 640, 512, 16)}
 dev = torch.device("cuda", 0)
 for name in (sys.argv[1:] or ["4k", "1280", "640"]):
-    h, w, B, nuniq = CFG[name]
-    uniq = synth.synth_batch(nuniq, h, w, seed0=0)
+    h, w, B, nuniq = CFG[name][:4]
+    uniq = synth.synth_batch(nuniq, h, w, seed0=CFG[name][4] if len(CFG[name]) > 4 else 0)
     d = torch.from_numpy(uniq.view(np.int16)).to(dev).repeat(B // nuniq, 1, 1)
     lab = torch.empty((B, h * w), dtype=torch.int32, device=dev)
     ex = D.PlaneExtractor(h, w, max_batch=B)
