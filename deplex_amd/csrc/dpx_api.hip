@@ -535,15 +535,15 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
     const int nbins = prm.hist_B * prm.hist_B;
     const int n_init = std::max(prm.C, nbins);
     const dim3 g_init(static_cast<unsigned>((n_init + 255) / 256), static_cast<unsigned>(batch));
-    const dim3 g_tab = cell_grid;  // (the occupied slots of the pair table: at most one per cell)
     const int sort_wgs = std::max(4, std::min(std::min(64, nbins), 2048 / std::max(1, batch)));
     hipLaunchKernelGGL(dpx::k_core_init, g_init, dim3(256), 0, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_core_link, cell_grid, dim3(256), 0, s, prm, cb);
-    hipLaunchKernelGGL(dpx::k_core_flatten, cell_grid, dim3(256), 0, s, prm, cb);
-    hipLaunchKernelGGL(dpx::k_pair_count, g_tab, dim3(256), 0, s, prm, cb);
-    hipLaunchKernelGGL(dpx::k_core_alloc, cell_grid, dim3(256), 0, s, prm, cb);
+    const dim3 prep_grid(static_cast<unsigned>((prm.C + dpx::kPrepT - 1) / dpx::kPrepT), static_cast<unsigned>(batch));
+    hipLaunchKernelGGL(dpx::k_core_flatten, prep_grid, dim3(dpx::kPrepT), 0, s, prm, cb);
+    hipLaunchKernelGGL(dpx::k_pair_count, prep_grid, dim3(dpx::kPrepT), static_cast<size_t>(nbins) * 4, s, prm, cb);
+    hipLaunchKernelGGL(dpx::k_core_alloc, prep_grid, dim3(dpx::kPrepT), 0, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_bin_scan, dim3(static_cast<unsigned>(batch)), dim3(64), 0, s, prm, cb);
-    hipLaunchKernelGGL(dpx::k_pair_scatter, g_tab, dim3(256), 0, s, prm, cb);
+    hipLaunchKernelGGL(dpx::k_pair_scatter, prep_grid, dim3(dpx::kPrepT), static_cast<size_t>(nbins) * 8, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_edge_scatter, cell_grid, dim3(256), 0, s, prm, cb);
     hipLaunchKernelGGL((dpx::k_bin_sort<false>), dim3(static_cast<unsigned>(std::min(sort_wgs, nbins)), static_cast<unsigned>(batch)), dim3(dpx::kBinSortT), static_cast<size_t>(dpx::kBinSortMax) * 8, s, prm, cb, static_cast<uint32_t*>(nullptr), dpx::kBinSortMax);
   }

@@ -205,21 +205,70 @@ __global__ __launch_bounds__(256) void k_core_link(Params prm, CoreBufs cb) {
   }
 }
 
-// root of every cell; per core: cells, one-way edges out; per (core, bin) pair: cells and leader
-__global__ __launch_bounds__(256) void k_core_flatten(Params prm, CoreBufs cb) {
+// Same-address atomics are served one after the other at the memory side (a few hundred ns each on this part, whether or
+// not the wave waits for the result), so a counter that every wave of a frame bumps costs (waves per frame) x that — 1 300
+// waves at 3840x2160, and a plane that covers most of a frame has every wave add to the same core and the same pair.  The
+// preparation launches therefore run 1024-thread workgroups and combine in LDS first: one atomic per workgroup and address.
+constexpr int kPrepT = 1024;
+// groups of a wave's lanes with equal keys: the group's first lane and its size, for every lane with `valid`
+__device__ __forceinline__ void wave_groups(uint32_t key, bool valid, int lane, int& lead, int& cnt) {
+  lead = lane;
+  cnt = 0;
+  unsigned long long todo = __ballot(valid);
+  while (todo) {
+    const int l = static_cast<int>(__builtin_ctzll(todo));
+    const uint32_t k0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(key), l));
+    const unsigned long long same = __ballot(valid && key == k0);
+    if (valid && key == k0) {
+      lead = l;
+      cnt = __popcll(same);
+    }
+    todo &= ~same;
+  }
+}
+constexpr int kAggN = 128;   // LDS slots for the cores / pairs that whole groups of a wave's lanes belong to
+constexpr int kAggMin = 16;  // lanes of a wave in one core (pair) from which the group goes through LDS
+// root of every cell; per core: cells, one-way edges out; per (core, bin) pair: cells and leader.  grid (ceil(C / 1024), B)
+__global__ __launch_bounds__(kPrepT) void k_core_flatten(Params prm, CoreBufs cb) {
+  __shared__ uint32_t s_ckey[kAggN], s_cval[kAggN], s_pkey[kAggN], s_pcnt[kAggN];
+  __shared__ unsigned long long s_pbest[kAggN];
+  __shared__ uint32_t s_misc[4];  // planar cells, new table slots of the workgroup, their first list position
   const int frame = blockIdx.y;
-  const int c = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
+  const int tid = threadIdx.x;
+  const int c = static_cast<int>(blockIdx.x) * kPrepT + tid;
   const size_t fo = static_cast<size_t>(frame) * prm.C;
-  const int lane = threadIdx.x & 63;
+  const int lane = tid & 63;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  if (tid < kAggN) {
+    s_ckey[tid] = kPairEmpty;
+    s_cval[tid] = 0u;
+    s_pkey[tid] = kPairEmpty;
+    s_pcnt[tid] = 0u;
+    s_pbest[tid] = ~0ull;
+  }
+  if (tid < 4) s_misc[tid] = 0u;
+  __syncthreads();
   const uint32_t m = c < prm.C ? cb.meta[fo + c] : 0u;
   const bool planar = (m & F_UNASSIGNED) != 0u;
   uint32_t* p = cb.parent + fo;
   uint32_t r = 0u, K = kPairEmpty;
   int nout = 0;
+  // Only the first cell of each of k_core_init's runs walks the forest (and compresses its path); the run's other cells —
+  // most cells of a plane — take the root from that lane and put it into their own entry with a write-through store: no
+  // pointer chase and no atomic for them, and the stores of a wave's 64 consecutive entries travel together.  (Nothing hooks
+  // roots during this launch, and a compression that meets the store can only write an ancestor: either order leaves the
+  // root, which is the minimum.)
+  {
+    const bool sym_r = planar && ((m >> 5) & (m >> 11) & 1u) != 0u;
+    const unsigned long long E = __ballot(sym_r);
+    const unsigned long long gaps = ~E & lt_mask;
+    const int run_start = gaps ? 64 - static_cast<int>(__builtin_clzll(gaps)) : 0;
+    const bool head = planar && run_start == lane;
+    if (head) r = cc_find(p, static_cast<uint32_t>(c));
+    r = static_cast<uint32_t>(__shfl(static_cast<int>(r), run_start));
+    if (planar && !head) cc_store(p + c, r);
+  }
   if (planar) {
-    r = cc_find(p, static_cast<uint32_t>(c));
-    atomicMin(p + c, r);  // (every cell's own entry: its root — an atomic like every other write to the forest)
     const int bn = static_cast<int>(m >> META_BIN_SHIFT);
     if (bn >= 1 && bn - 1 < prm.hist_B * prm.hist_B) K = (r << kPairBinBits) | static_cast<uint32_t>(bn - 1);
     const uint32_t ow = ((m >> 2) & ~(m >> 8)) & 0xFu;  // one-way out-edges
@@ -233,101 +282,216 @@ __global__ __launch_bounds__(256) void k_core_flatten(Params prm, CoreBufs cb) {
     }
   }
   if (nout) atomicAdd(cb.noe + fo + r, static_cast<uint32_t>(nout));
-  // neighbouring cells mostly share their core and bin: one atomic per distinct (core) / (core, bin) of the wave — a plane
-  // of 70 000 cells would otherwise put 70 000 atomics on one address
-  unsigned long long todo = __ballot(planar);
-  if (lane == 0 && todo) atomicAdd(cb.cursor + 4 * frame + 2, static_cast<uint32_t>(__popcll(todo)));
-  while (todo) {
-    const int l = static_cast<int>(__builtin_ctzll(todo));
-    const uint32_t r0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(r), l));
-    const unsigned long long same = __ballot(planar && r == r0) & todo;
-    if (lane == l) atomicAdd(cb.csize + fo + r0, static_cast<uint32_t>(__popcll(same)));
-    todo &= ~same;
+  // neighbouring cells mostly share their core and bin: one operation per distinct core / (core, bin) of the wave, in LDS
+  // where the group is large (a plane's interior: the other waves of the workgroup have the same), in memory otherwise.  The
+  // groups are found first (registers only); then every group's first lane works at the same time — a loop with an atomic
+  // per group would wait for up to 64 round trips to memory in a row where no two cells share a core.
+  const unsigned long long pmask = __ballot(planar);
+  if (lane == 0 && pmask) atomicAdd(&s_misc[0], static_cast<uint32_t>(__popcll(pmask)));
+  int lead_r, n_r;
+  wave_groups(r, planar, lane, lead_r, n_r);
+  if (planar && lane == lead_r) {
+    bool in_lds = false;
+    if (n_r >= kAggMin) {
+      const uint32_t hs = (r * 2654435761u) >> 25;  // 7 bits: kAggN slots
+      const uint32_t old = atomicCAS(&s_ckey[hs], kPairEmpty, r);
+      if (old == kPairEmpty || old == r) {
+        atomicAdd(&s_cval[hs], static_cast<uint32_t>(n_r));
+        in_lds = true;
+      }
+    }
+    if (!in_lds) atomicAdd(cb.csize + fo + r, static_cast<uint32_t>(n_r));
   }
   uint32_t* hkey = cb.hkey + static_cast<size_t>(frame) * cb.T;
-  const unsigned long long val = K != kPairEmpty
-                                     ? (static_cast<unsigned long long>(sort_mse_key(cb.mse_c[fo + c])) << kCellBits) | static_cast<unsigned long long>(c)
-                                     : ~0ull;
-  todo = __ballot(K != kPairEmpty);
+  const bool has_k = K != kPairEmpty;
+  const unsigned long long val = has_k ? (static_cast<unsigned long long>(sort_mse_key(cb.mse_c[fo + c])) << kCellBits) | static_cast<unsigned long long>(c)
+                                       : ~0ull;
+  int lead_k, n_k;
+  wave_groups(K, has_k, lane, lead_k, n_k);
+  const bool big_k = has_k && n_k >= kAggMin;
+  // a large group's leader (minimum of mse key | cell) as one value, at the group's first lane (at most four such groups)
+  unsigned long long vmin = val;
+  for (unsigned long long bl = __ballot(big_k && lane == lead_k); bl; bl &= bl - 1ull) {
+    const int l = static_cast<int>(__builtin_ctzll(bl));
+    unsigned long long v = (has_k && lead_k == l) ? val : ~0ull;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned long long o = __shfl_xor(v, off);
+      v = o < v ? o : v;
+    }
+    if (lane == l) vmin = v;
+  }
   bool mynew = false;
   uint32_t newslot = 0u;
-  while (todo) {
-    const int l = static_cast<int>(__builtin_ctzll(todo));
-    const uint32_t K0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(K), l));
-    const bool mine = K == K0 && ((todo >> lane) & 1ull) != 0ull;
-    const unsigned long long same = __ballot(mine);
-    uint32_t slot = 0u;
-    if (lane == l) {
-      slot = pair_slot(hkey, cb.logT, K0, &mynew);
-      newslot = slot;
-      atomicAdd(cb.hcnt + static_cast<size_t>(frame) * cb.T + slot, static_cast<uint32_t>(__popcll(same)));
+  if (has_k && lane == lead_k) {
+    bool in_lds = false;
+    if (big_k) {
+      const uint32_t hs = (K * 2654435761u) >> 25;
+      const uint32_t old = atomicCAS(&s_pkey[hs], kPairEmpty, K);
+      if (old == kPairEmpty || old == K) {
+        atomicAdd(&s_pcnt[hs], static_cast<uint32_t>(n_k));
+        atomicMin(&s_pbest[hs], vmin);
+        in_lds = true;
+      }
     }
-    slot = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(slot), l));
-    if (mine) {
-      unsigned long long* hb = cb.hbest + static_cast<size_t>(frame) * cb.T + slot;
+    if (!in_lds) {
+      newslot = pair_slot(hkey, cb.logT, K, &mynew);
+      atomicAdd(cb.hcnt + static_cast<size_t>(frame) * cb.T + newslot, static_cast<uint32_t>(n_k));
+      if (big_k) {
+        unsigned long long* hb = cb.hbest + static_cast<size_t>(frame) * cb.T + newslot;
+        if (vmin < __hip_atomic_load(hb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(hb, vmin);
+      }
+    }
+  }
+  {
+    const uint32_t gslot = static_cast<uint32_t>(__shfl(static_cast<int>(newslot), has_k ? lead_k : lane));
+    if (has_k && !big_k) {
+      unsigned long long* hb = cb.hbest + static_cast<size_t>(frame) * cb.T + gslot;
       if (val < __hip_atomic_load(hb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(hb, val);
     }
-    todo &= ~same;
   }
-  // the slots this wave has newly occupied go to the frame's slot list: one atomic per wave
-  const unsigned long long newmask = __ballot(mynew);
-  if (newmask) {
-    uint32_t base = 0u;
-    const int first = static_cast<int>(__builtin_ctzll(newmask));
-    if (lane == first) base = atomicAdd(cb.cursor + 4 * frame + 3, static_cast<uint32_t>(__popcll(newmask)));
-    base = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(base), first));
-    if (mynew) cb.hslots[fo + base + static_cast<uint32_t>(__popcll(newmask & lt_mask))] = newslot;
+  __syncthreads();
+  // what the workgroup combined goes to memory: one atomic per core / pair
+  bool mynew2 = false;
+  uint32_t newslot2 = 0u;
+  if (tid < kAggN) {
+    if (s_ckey[tid] != kPairEmpty) atomicAdd(cb.csize + fo + s_ckey[tid], s_cval[tid]);
+    if (s_pkey[tid] != kPairEmpty) {
+      newslot2 = pair_slot(hkey, cb.logT, s_pkey[tid], &mynew2);
+      atomicAdd(cb.hcnt + static_cast<size_t>(frame) * cb.T + newslot2, s_pcnt[tid]);
+      unsigned long long* hb = cb.hbest + static_cast<size_t>(frame) * cb.T + newslot2;
+      const unsigned long long v = s_pbest[tid];
+      if (v < __hip_atomic_load(hb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(hb, v);
+    }
   }
+  // the slots this workgroup has newly occupied go to the frame's slot list: one atomic per workgroup
+  const unsigned long long nm1 = __ballot(mynew), nm2 = __ballot(mynew2);
+  const int n1 = __popcll(nm1), n2 = __popcll(nm2);
+  uint32_t woff = 0u;
+  if (lane == 0 && n1 + n2) woff = atomicAdd(&s_misc[1], static_cast<uint32_t>(n1 + n2));
+  woff = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(woff)));
+  __syncthreads();
+  if (tid == 0) {
+    if (s_misc[0]) atomicAdd(cb.cursor + 4 * frame + 2, s_misc[0]);
+    if (s_misc[1]) s_misc[2] = atomicAdd(cb.cursor + 4 * frame + 3, s_misc[1]);
+  }
+  __syncthreads();
+  const uint32_t base = s_misc[2] + woff;
+  if (mynew) cb.hslots[fo + base + static_cast<uint32_t>(__popcll(nm1 & lt_mask))] = newslot;
+  if (mynew2) cb.hslots[fo + base + static_cast<uint32_t>(n1 + __popcll(nm2 & lt_mask))] = newslot2;
 }
 
-// grid (ceil(C / 256), B) over the list of occupied slots: every pair counts for its core
-__global__ __launch_bounds__(256) void k_pair_count(Params prm, CoreBufs cb) {
+// grid (ceil(C / 1024), B) over the list of occupied slots, 4 * bins bytes of LDS: every pair counts for its core and its bin
+__global__ __launch_bounds__(kPrepT) void k_pair_count(Params prm, CoreBufs cb) {
+  extern __shared__ uint32_t s_bins[];
   const int frame = blockIdx.y;
-  const int li = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
-  if (li >= static_cast<int>(cb.cursor[4 * frame + 3])) return;
-  const uint32_t K = cb.hkey[static_cast<size_t>(frame) * cb.T + cb.hslots[static_cast<size_t>(frame) * prm.C + li]];
-  atomicAdd(cb.npairs + static_cast<size_t>(frame) * prm.C + (K >> kPairBinBits), 1u);
-  atomicAdd(cb.pbcnt + static_cast<size_t>(frame) * (prm.hist_B * prm.hist_B) + (K & kPairBinMask), 1u);
+  const int npair = static_cast<int>(cb.cursor[4 * frame + 3]);
+  if (static_cast<int>(blockIdx.x) * kPrepT >= npair) return;  // (the whole workgroup)
+  const int nb = prm.hist_B * prm.hist_B;
+  for (int b = threadIdx.x; b < nb; b += kPrepT) s_bins[b] = 0u;
+  __syncthreads();
+  const int li = static_cast<int>(blockIdx.x) * kPrepT + threadIdx.x;
+  if (li < npair) {
+    const uint32_t K = cb.hkey[static_cast<size_t>(frame) * cb.T + cb.hslots[static_cast<size_t>(frame) * prm.C + li]];
+    atomicAdd(cb.npairs + static_cast<size_t>(frame) * prm.C + (K >> kPairBinBits), 1u);
+    atomicAdd(&s_bins[K & kPairBinMask], 1u);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nb; b += kPrepT)
+    if (s_bins[b]) atomicAdd(cb.pbcnt + static_cast<size_t>(frame) * nb + b, s_bins[b]);
 }
 
-// grid (ceil(C / 256), B): room for every core's pairs and one-way edges
-__global__ __launch_bounds__(256) void k_core_alloc(Params prm, CoreBufs cb) {
+// grid (ceil(C / 1024), B): room for every core's pairs and one-way edges; one atomic per workgroup and counter
+__global__ __launch_bounds__(kPrepT) void k_core_alloc(Params prm, CoreBufs cb) {
+  __shared__ uint32_t s_tot[2 * (kPrepT / 64)];
+  __shared__ uint32_t s_base[2];
   const int frame = blockIdx.y;
-  const int c = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
-  if (c >= prm.C) return;
+  const int c = static_cast<int>(blockIdx.x) * kPrepT + threadIdx.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const size_t fo = static_cast<size_t>(frame) * prm.C;
-  if (cb.csize[fo + c] == 0u) return;  // (only roots of planar cores have a size)
-  const uint32_t ps = atomicAdd(cb.cursor + 4 * frame, cb.npairs[fo + c]);
+  const bool root = c < prm.C && cb.csize[fo + c] != 0u;  // (only roots of planar cores have a size)
+  // the workgroup's cores take consecutive ranges: prefix sums over the lanes, then over the waves
+  const uint32_t np = root ? cb.npairs[fo + c] : 0u, ne = root ? cb.noe[fo + c] : 0u;
+  uint32_t sp = np, se = ne;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t a = static_cast<uint32_t>(__shfl_up(static_cast<int>(sp), off)), b = static_cast<uint32_t>(__shfl_up(static_cast<int>(se), off));
+    if (lane >= off) {
+      sp += a;
+      se += b;
+    }
+  }
+  if (lane == 63) {
+    s_tot[2 * wid] = sp;
+    s_tot[2 * wid + 1] = se;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tp = 0u, te = 0u;
+    for (int w = 0; w < kPrepT / 64; ++w) {
+      const uint32_t a = s_tot[2 * w], b = s_tot[2 * w + 1];
+      s_tot[2 * w] = tp;
+      s_tot[2 * w + 1] = te;
+      tp += a;
+      te += b;
+    }
+    s_base[0] = tp ? atomicAdd(cb.cursor + 4 * frame, tp) : 0u;
+    s_base[1] = te ? atomicAdd(cb.cursor + 4 * frame + 1, te) : 0u;
+  }
+  __syncthreads();
+  if (!root) return;
+  const uint32_t ps = s_base[0] + s_tot[2 * wid] + sp - np, es = ne ? s_base[1] + s_tot[2 * wid + 1] + se - ne : 0u;
   cb.pstart[fo + c] = ps;
-  const uint32_t ne = cb.noe[fo + c];
-  const uint32_t es = ne ? atomicAdd(cb.cursor + 4 * frame + 1, ne) : 0u;
   cb.oestart[fo + c] = es;
   cb.crec[fo + ps] = make_uint2(es, ne);
 }
 
-// grid (ceil(C / 256), B) over the list of occupied slots: pairs into their core's list + their sort key into its bin's segment
-__global__ __launch_bounds__(256) void k_pair_scatter(Params prm, CoreBufs cb) {
+// grid (ceil(C / 1024), B) over the list of occupied slots, 8 * bins bytes of LDS: pairs into their core's list + their sort
+// key into its bin's segment.  A workgroup's pairs of one bin take consecutive slots of the segment: ranks from an LDS counter
+// per bin, then one atomic per (workgroup, bin) on the frame's cursor — a hot bin holds thousands of pairs.
+__global__ __launch_bounds__(kPrepT) void k_pair_scatter(Params prm, CoreBufs cb) {
+  extern __shared__ uint32_t s_bins[];  // [bins] pairs of the workgroup -> first slot; [bins] their cells
   const int frame = blockIdx.y;
-  const int i = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
+  const int npair = static_cast<int>(cb.cursor[4 * frame + 3]);
+  if (static_cast<int>(blockIdx.x) * kPrepT >= npair) return;  // (the whole workgroup)
+  const int nb = prm.hist_B * prm.hist_B;
+  uint32_t* s_cnt = s_bins;
+  uint32_t* s_cells = s_bins + nb;
+  for (int b = threadIdx.x; b < 2 * nb; b += kPrepT) s_bins[b] = 0u;
+  __syncthreads();
+  const int i = static_cast<int>(blockIdx.x) * kPrepT + threadIdx.x;
   const size_t fo = static_cast<size_t>(frame) * prm.C;
-  if (i < static_cast<int>(cb.cursor[4 * frame + 3])) {
-    const size_t to = static_cast<size_t>(frame) * cb.T + cb.hslots[fo + i];
+  const size_t bo = static_cast<size_t>(frame) * nb;
+  const bool act = i < npair;
+  size_t to = 0;
+  uint32_t root = 0u, bin = 0u, cnt = 0u, rank = 0u;
+  if (act) {
+    to = static_cast<size_t>(frame) * cb.T + cb.hslots[fo + i];
     const uint32_t K = cb.hkey[to];
-    {
-      const uint32_t root = K >> kPairBinBits, bin = K & kPairBinMask;
-      const uint32_t cnt = cb.hcnt[to];
-      const uint32_t j = cb.pstart[fo + root] + atomicAdd(cb.pfill + fo + root, 1u);
-      cb.corepairs[fo + j] = bin | (cnt << kPairBinBits);
-      // counting sort by bin: the pair's key goes to the next free slot of its bin's segment (k_bin_sort orders the segment)
-      const size_t bo = static_cast<size_t>(frame) * (prm.hist_B * prm.hist_B);
-      const uint32_t at = cb.bin_off[bo + frame + bin] + atomicAdd(cb.pbcnt + bo + bin, 1u);
-      cb.keys[static_cast<size_t>(frame) * cb.Cpad + at] = cb.hbest[to];  // mse key << 19 | leader cell
-      atomicAdd(cb.histg + bo + bin, cnt);
-      // the slot is empty again for the next call (write-through: the next call's atomics must find these values in memory)
-      cc_store(cb.hkey + to, kPairEmpty);
-      cc_store(cb.hcnt + to, 0u);
-      cc_store64(cb.hbest + to, ~0ull);
+    root = K >> kPairBinBits;
+    bin = K & kPairBinMask;
+    cnt = cb.hcnt[to];
+    rank = atomicAdd(&s_cnt[bin], 1u);
+    atomicAdd(&s_cells[bin], cnt);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nb; b += kPrepT) {
+    const uint32_t n = s_cnt[b];
+    if (n) {
+      s_cnt[b] = atomicAdd(cb.pbcnt + bo + b, n);
+      atomicAdd(cb.histg + bo + b, s_cells[b]);
     }
+  }
+  __syncthreads();
+  if (act) {
+    const uint32_t j = cb.pstart[fo + root] + atomicAdd(cb.pfill + fo + root, 1u);
+    cb.corepairs[fo + j] = bin | (cnt << kPairBinBits);
+    const uint32_t at = cb.bin_off[bo + frame + bin] + s_cnt[bin] + rank;
+    cb.keys[static_cast<size_t>(frame) * cb.Cpad + at] = cb.hbest[to];  // mse key << 19 | leader cell (k_bin_sort orders the segment)
+    // the slot is empty again for the next call (write-through: the next call's atomics must find these values in memory)
+    cc_store(cb.hkey + to, kPairEmpty);
+    cc_store(cb.hcnt + to, 0u);
+    cc_store64(cb.hbest + to, ~0ull);
   }
 }
 
