@@ -528,7 +528,7 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   if (prof) DPX_HIP(hipEventRecord(ev[2], s));
   const long long total = static_cast<long long>(batch) * prm.C;
   if (total > 0 && h->regions_tier != 2)
-    hipLaunchKernelGGL(dpx::k_cellgraph, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, s, prm, h->d_cells, h->d_meta, h->d_mse_c);
+    hipLaunchKernelGGL(dpx::k_cellgraph, dim3(static_cast<unsigned>((total + 2047) / 2048 * 8)), dim3(256), 0, s, prm, h->d_cells, h->d_meta, h->d_mse_c);  // (a multiple of 8 workgroups: one contiguous range of cells per XCD)
   const dim3 cell_grid(static_cast<unsigned>((prm.C + 255) / 256), static_cast<unsigned>(batch));
   if (total > 0 && h->cores && !skip_r) {  // cores of the symmetric edges and their (core, bin) pairs (dpx_regions3.h), before the seed lists
     const dpx::CoreBufs cb = core_bufs(h);
@@ -612,7 +612,8 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
       rx.candfit = h->d_candfit;
       hipLaunchKernelGGL((dpx::k_seg_accum<true>), dim3(per_frame_huge, batch), dim3(dpx::kAccWaves * 64), 0, s, prm, tb);
       CHK("k_seg_accum<huge>");
-      hipLaunchKernelGGL((dpx::k_seg_accum<false>), dim3(per_frame, batch), dim3(dpx::kAccWaves * 64), 0, s, prm, tb);
+      const int per_frame_acc = std::max(1, std::min(32, 2048 / std::max(1, batch)));
+      hipLaunchKernelGGL((dpx::k_seg_accum<false>), dim3(per_frame_acc, batch), dim3(dpx::kAccWaves * 64), 0, s, prm, tb);
       CHK("k_seg_accum");
       hipLaunchKernelGGL(dpx::k_seg_fit, dim3(static_cast<unsigned>((h->pcap + 255) / 256), static_cast<unsigned>(batch)), dim3(256), 0, s, prm, tb);
       CHK("k_seg_fit");
@@ -1490,7 +1491,7 @@ int dpx_get_cell_edges(dpx_handle h, int32_t frame, uint8_t* out) {
     dpx::Params prm = h->prm;
     prm.batch = h->last_batch;
     const long long total = static_cast<long long>(prm.batch) * prm.C;
-    hipLaunchKernelGGL(dpx::k_cellgraph, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, h->last_stream, prm, h->d_cells, h->d_meta, h->d_mse_c);
+    hipLaunchKernelGGL(dpx::k_cellgraph, dim3(static_cast<unsigned>((total + 2047) / 2048 * 8)), dim3(256), 0, h->last_stream, prm, h->d_cells, h->d_meta, h->d_mse_c);
     DPX_HIP(hipStreamSynchronize(h->last_stream));
   }
   if (C) DPX_HIP(hipMemcpy(tmp.data(), h->d_meta + frame * C, C * 4, hipMemcpyDeviceToHost));

@@ -1664,7 +1664,7 @@ struct TailBufs {
   int* task;               // [B][4]: 2 = segments of k_seg_accum<false>, 3 = of k_seg_accum<true>
   int pcap;
 };
-constexpr int kAccWaves = 4, kAccStage = 64;
+constexpr int kAccWaves = 4, kAccStage = 64, kAccChunk = 4;
 constexpr int kAccRound = 12, kAccRing = 2 * kAccRound;  // chunks per round of the huge-segment form, buffers in its ring
 
 template <bool HUGE>
@@ -1685,10 +1685,13 @@ __global__ __launch_bounds__(kAccWaves * 64) void k_seg_accum(Params prm, TailBu
     __shared__ __align__(16) float s_stage[kAccWaves][kStage * 9];  // (read back 16 bytes at a time)
     float* st = s_stage[wid];
     for (int guard = 0; guard <= ncand; ++guard) {  // (a wave can take at most every segment once)
-      int ci = 0;
-      if (lane == 0) ci = atomicAdd(tb.task + 4 * frame + 2, 1);
-      ci = __builtin_amdgcn_readfirstlane(ci);
-      if (ci >= ncand) break;
+      // (kAccChunk segments per pull: the frame's counter serves its atomics one after the other, ~100 ns each)
+      int c0 = 0;
+      if (lane == 0) c0 = atomicAdd(tb.task + 4 * frame + 2, kAccChunk);
+      c0 = __builtin_amdgcn_readfirstlane(c0);
+      if (c0 >= ncand) break;
+      const int c1 = c0 + kAccChunk < ncand ? c0 + kAccChunk : ncand;
+      for (int ci = c0; ci < c1; ++ci) {
       const uint4 cg = cand_grow[ci];
       const int gi = static_cast<int>(cg.x), gs = static_cast<int>(cg.y), ge = static_cast<int>(cg.z);
       if (__builtin_amdgcn_readfirstlane(ge - gs) < kHugeMin) {  // (the huge ones are the other launch's)
@@ -1737,6 +1740,7 @@ __global__ __launch_bounds__(kAccWaves * 64) void k_seg_accum(Params prm, TailBu
       if (lane < 9) co[lane] = acc;
       if (lane == 9) co[9] = __int_as_float((ge - gs + 1) * prm.n);
       if (lane == 10) co[10] = __int_as_float(gi);
+      }
       }
     }
   } else {
