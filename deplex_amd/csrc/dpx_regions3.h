@@ -76,8 +76,11 @@ struct CoreBufs {
 // never written with plain stores: the per-XCD L2s are not coherent with each other, atomics execute at the memory side,
 // and a plain store stays in the storing XCD's L2 as a dirty line whose later write-back would put the old value over an
 // atomic's result (seen as a lost union: one frame in ~100 under load).  Write-through (sc1) stores leave no such line.
+#ifndef DPX_CC_LOAD_SCOPE
+#define DPX_CC_LOAD_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#endif
 __device__ __forceinline__ uint32_t cc_load(const uint32_t* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, DPX_CC_LOAD_SCOPE);
 }
 __device__ __forceinline__ void cc_store(uint32_t* p, uint32_t v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -100,11 +103,15 @@ __device__ __forceinline__ uint32_t cc_find(uint32_t* p, uint32_t x) {
     if (q == r) break;
     r = q;
   }
+#ifdef DPX_CC_SELF_ONLY
+  if (x != r && cc_load(p + x) > r) atomicMin(p + x, r);
+#else
   while (x != r) {  // compression
     const uint32_t nx = cc_load(p + x);
     if (nx > r) atomicMin(p + x, r);
     x = nx < x ? nx : r;
   }
+#endif
   return r;
 }
 __device__ __forceinline__ void cc_union(uint32_t* p, uint32_t a, uint32_t b) {
@@ -141,23 +148,12 @@ __device__ __forceinline__ uint32_t pair_slot(uint32_t* hkey, int logT, uint32_t
   }
 }
 
-// grid (ceil(max(C, bins) / 256), B), 256 threads
+// grid (ceil(max(C, bins) / 256), B), 256 threads: the per-cell and per-bin counters of the preparation start at zero
+// (write-through, like every store that a later launch's atomics must find in memory)
 __global__ __launch_bounds__(256) void k_core_init(Params prm, CoreBufs cb) {
   const int frame = blockIdx.y;
   const int i = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
   const size_t fo = static_cast<size_t>(frame) * prm.C;
-  // The forest starts with the horizontal runs of each wave's 64 cells already joined: a cell's first parent is the first
-  // cell of its run of symmetric right-edges inside the wave (bit tricks on one ballot) — most of a plane's unions for free.
-  {
-    const uint32_t m = i < prm.C ? cb.meta[fo + i] : 0u;
-    const bool planar = (m & F_UNASSIGNED) != 0u;
-    const bool sym_r = planar && ((m >> 5) & (m >> 11) & 1u) != 0u;  // out- and in-edge R
-    const int lane = threadIdx.x & 63;
-    const unsigned long long E = __ballot(sym_r);                        // bit l: lanes l and l + 1 are joined
-    const unsigned long long gaps = ~E & ((1ull << lane) - 1ull);        // missing joins below this lane
-    const int run_start = gaps ? 64 - static_cast<int>(__builtin_clzll(gaps)) : 0;
-    if (i < prm.C) cc_store(cb.parent + fo + i, static_cast<uint32_t>(planar ? i - lane + run_start : i));
-  }
   if (i < prm.C) {
     cc_store(cb.csize + fo + i, 0u);
     cc_store(cb.npairs + fo + i, 0u);
@@ -180,29 +176,91 @@ __global__ __launch_bounds__(256) void k_core_init(Params prm, CoreBufs cb) {
   }
 }
 
-// The unions the initial runs do not cover: the right-edge of a wave's last lane, and the down-edges — except a down-edge
-// whose left neighbour is in the same run, has a down-edge too, and whose two lower cells are joined by a right-edge: that
-// union is implied by the left neighbour's.
-__global__ __launch_bounds__(256) void k_core_link(Params prm, CoreBufs cb) {
-  const int frame = blockIdx.y;
-  const int c = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
-  const size_t fo = static_cast<size_t>(frame) * prm.C;
-  const int lane = threadIdx.x & 63;
-  const uint32_t m = c < prm.C ? cb.meta[fo + c] : 0u;
-  const bool planar = (m & F_UNASSIGNED) != 0u;
-  const uint32_t sym = planar ? (((m >> 2) & (m >> 8)) & 0xFu) : 0u;  // out-edge and in-edge: dir 0..3 = U, D, L, R
-  const bool sym_r = (sym & 8u) != 0u, sym_d = (sym & 2u) != 0u;
-  const unsigned long long E = __ballot(sym_r), Dm = __ballot(sym_d);
-  uint32_t* p = cb.parent + fo;
-  if (sym_r && lane == 63) cc_union(p, static_cast<uint32_t>(c), static_cast<uint32_t>(c + 1));
-  if (sym_d) {
-    bool implied = false;
-    if (lane > 0 && ((E >> (lane - 1)) & 1ull) && ((Dm >> (lane - 1)) & 1ull)) {
-      const uint32_t ml = cb.meta[fo + c + prm.nh - 1];  // the cell below the left neighbour
-      implied = ((ml >> 5) & (ml >> 11) & 1u) != 0u;
-    }
-    if (!implied) cc_union(p, static_cast<uint32_t>(c), static_cast<uint32_t>(c + prm.nh));
+// ---- cores, first level: 32 x 32-cell tiles joined in LDS ---------------------------------------------------------------
+// A workgroup takes one tile, joins its cells along the symmetric edges with the same union-find in LDS (hooking by
+// compare-and-swap, parents always lower than children — local index order is cell index order inside a tile), and writes
+// every cell's tile root into the forest.  What is left for memory are the edges across tile borders (k_core_link): 1/16 of
+// the unions, on trees that are at most (tiles of the frame) deep instead of (wave runs of the frame).
+constexpr int kTile = 32;
+__device__ __forceinline__ uint32_t lds_find(volatile uint32_t* lp, uint32_t x) {
+  for (;;) {
+    const uint32_t q = lp[x];
+    if (q == x) return x;
+    x = q;
   }
+}
+// grid (tiles across * tiles down, B), 1024 threads
+__global__ __launch_bounds__(kTile * kTile) void k_core_tiles(Params prm, CoreBufs cb) {
+  __shared__ uint32_t lp[kTile * kTile];
+  const int frame = blockIdx.y;
+  const int tiles_x = (prm.nh + kTile - 1) / kTile;
+  const int bx = static_cast<int>(blockIdx.x) % tiles_x, by = static_cast<int>(blockIdx.x) / tiles_x;
+  const int t = threadIdx.x, tx = t & (kTile - 1), ty = t >> 5;
+  const int X = bx * kTile + tx, Y = by * kTile + ty;
+  const bool inside = X < prm.nh && Y < prm.nv;
+  const int c = Y * prm.nh + X;
+  const size_t fo = static_cast<size_t>(frame) * prm.C;
+  const uint32_t m = inside ? cb.meta[fo + c] : 0u;
+  const bool planar = (m & F_UNASSIGNED) != 0u;
+  const bool sym_r = planar && tx + 1 < kTile && ((m >> 5) & (m >> 11) & 1u) != 0u;  // out- and in-edge R, inside the tile
+  const bool sym_d = planar && ty + 1 < kTile && ((m >> 3) & (m >> 9) & 1u) != 0u;   // out- and in-edge D, inside the tile
+  {
+    // horizontal runs for free: a wave holds two tile rows; a cell's first parent is the first cell of its run of joined
+    // right-edges (bit tricks on one ballot; sym_r is never set in a row's last column, so runs end with their row)
+    const int lane = t & 63;
+    const unsigned long long E = __ballot(sym_r);
+    const unsigned long long gaps = ~E & ((1ull << lane) - 1ull);
+    const int run_start = gaps ? 64 - static_cast<int>(__builtin_clzll(gaps)) : 0;
+    lp[t] = static_cast<uint32_t>(t - lane + run_start);
+  }
+  __syncthreads();
+  if (sym_d) {  // (most of these find both ends joined already: LDS round trips, no memory)
+    uint32_t a = static_cast<uint32_t>(t), b = static_cast<uint32_t>(t + kTile);
+    for (;;) {
+      a = lds_find(lp, a);
+      b = lds_find(lp, b);
+      if (a == b) break;
+      if (a < b) {
+        const uint32_t x = a;
+        a = b;
+        b = x;
+      }
+      const uint32_t old = atomicCAS(&lp[a], a, b);
+      if (old == a) break;
+      a = old;
+    }
+  }
+  __syncthreads();
+  if (inside) {
+    const uint32_t lr = planar ? lds_find(lp, static_cast<uint32_t>(t)) : static_cast<uint32_t>(t);
+    cc_store(cb.parent + fo + c, static_cast<uint32_t>((by * kTile + static_cast<int>(lr >> 5)) * prm.nh + bx * kTile + static_cast<int>(lr & (kTile - 1))));
+  }
+}
+
+// The unions across tile borders.  grid (tiles, B), 64 threads: lanes 0..31 the tile's bottom row (down-edges), lanes 32..63
+// its right column (right-edges).  An edge is left out when the previous cell along the border has the same tile root and
+// an edge too, and the two cells across have the same tile root as each other: that union is implied by the previous one.
+__global__ __launch_bounds__(64) void k_core_link(Params prm, CoreBufs cb) {
+  const int frame = blockIdx.y;
+  const int tiles_x = (prm.nh + kTile - 1) / kTile;
+  const int bx = static_cast<int>(blockIdx.x) % tiles_x, by = static_cast<int>(blockIdx.x) / tiles_x;
+  const int lane = threadIdx.x, k = lane & (kTile - 1);
+  const bool down = lane < kTile;
+  const int X = bx * kTile + (down ? k : kTile - 1), Y = by * kTile + (down ? kTile - 1 : k);
+  const size_t fo = static_cast<size_t>(frame) * prm.C;
+  const bool inside = X < prm.nh && Y < prm.nv;
+  const int c = Y * prm.nh + X;
+  const int step = down ? prm.nh : 1;   // to the cell across the border
+  const int prev = down ? 1 : prm.nh;   // back along the border
+  const uint32_t m = inside ? cb.meta[fo + c] : 0u;
+  const bool edge = (m & F_UNASSIGNED) != 0u && (down ? ((m >> 3) & (m >> 9) & 1u) : ((m >> 5) & (m >> 11) & 1u)) != 0u;
+  uint32_t* p = cb.parent + fo;
+  // (the tile roots are the previous launch's plain results: ordinary loads)
+  const uint32_t mine = edge ? cb.parent[fo + c] : 0xFFFFFFFFu, across = edge ? cb.parent[fo + c + step] : 0xFFFFFFFFu;
+  const uint32_t mine_prev = static_cast<uint32_t>(__shfl_up(static_cast<int>(mine), 1)), across_prev = static_cast<uint32_t>(__shfl_up(static_cast<int>(across), 1));
+  (void)prev;
+  const bool implied = edge && k > 0 && mine_prev == mine && across_prev == across;  // (lane - 1 is the previous cell of the same border: k > 0)
+  if (edge && !implied) cc_union(p, static_cast<uint32_t>(c), static_cast<uint32_t>(c + step));
 }
 
 // Same-address atomics are served one after the other at the memory side (a few hundred ns each on this part, whether or
@@ -253,20 +311,18 @@ __global__ __launch_bounds__(kPrepT) void k_core_flatten(Params prm, CoreBufs cb
   uint32_t* p = cb.parent + fo;
   uint32_t r = 0u, K = kPairEmpty;
   int nout = 0;
-  // Only the first cell of each of k_core_init's runs walks the forest (and compresses its path); the run's other cells —
-  // most cells of a plane — take the root from that lane and put it into their own entry with a write-through store: no
-  // pointer chase and no atomic for them, and the stores of a wave's 64 consecutive entries travel together.  (Nothing hooks
-  // roots during this launch, and a compression that meets the store can only write an ancestor: either order leaves the
-  // root, which is the minimum.)
+  // Cells of one tile component share their entry (the tile root, k_core_tiles): one lane per distinct entry of the wave walks
+  // the forest from there (and compresses its path), the others take the root from that lane and put it into their own entry
+  // with a write-through store: no pointer chase and no atomic for most cells of a plane, and the stores of a wave's 64
+  // consecutive entries travel together.  (Nothing hooks roots during this launch, and a compression that meets the store
+  // can only write an ancestor: either order leaves the root, which is the minimum.)
   {
-    const bool sym_r = planar && ((m >> 5) & (m >> 11) & 1u) != 0u;
-    const unsigned long long E = __ballot(sym_r);
-    const unsigned long long gaps = ~E & lt_mask;
-    const int run_start = gaps ? 64 - static_cast<int>(__builtin_clzll(gaps)) : 0;
-    const bool head = planar && run_start == lane;
-    if (head) r = cc_find(p, static_cast<uint32_t>(c));
-    r = static_cast<uint32_t>(__shfl(static_cast<int>(r), run_start));
-    if (planar && !head) cc_store(p + c, r);
+    const uint32_t tr = planar ? cb.parent[fo + c] : 0u;  // (the entry as the earlier launches left it: at least the tile root)
+    int lead_t, n_t;
+    wave_groups(tr, planar, lane, lead_t, n_t);
+    if (planar && lane == lead_t) r = cc_find(p, tr);
+    r = static_cast<uint32_t>(__shfl(static_cast<int>(r), lead_t));
+    if (planar && tr != r) cc_store(p + c, r);
   }
   if (planar) {
     const int bn = static_cast<int>(m >> META_BIN_SHIFT);
