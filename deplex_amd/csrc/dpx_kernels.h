@@ -486,37 +486,47 @@ __global__ __launch_bounds__(256) void k_cellgraph(Params prm, const dpx_cell* _
   const int frame = static_cast<int>(gid / prm.C);
   const int c = static_cast<int>(gid - static_cast<long long>(frame) * prm.C);
   const int cr = c / prm.nh, cc = c - cr * prm.nh;
-  const dpx_cell* fc = cells + static_cast<long long>(frame) * prm.C;
-  const uint32_t info = fc[c].info;
+  // Everything the four tests read is fetched up front, unconditionally (a missing neighbour reads the cell itself): the
+  // own record's three quarters that matter and the same of the four neighbours, fifteen 16-byte loads in flight at once.
+  // With the loads behind the tests' branches a wave made up to ten dependent round trips to memory.
+  const float4* f4 = reinterpret_cast<const float4*>(cells + static_cast<long long>(frame) * prm.C);
+  const int nb[4] = {cr >= 1 ? c - prm.nh : -1, cr + 1 < prm.nv ? c + prm.nh : -1, cc >= 1 ? c - 1 : -1, cc + 1 < prm.nh ? c + 1 : -1};
+  const float4 o0 = f4[4 * c], o2 = f4[4 * c + 2], o3 = f4[4 * c + 3];  // (sum, pp0) (pp5, normal) (d, mse, tol, info)
+  float4 v0[4], v2[4], v3[4];
+#pragma unroll
+  for (int dir = 0; dir < 4; ++dir) {
+    const int v = nb[dir] >= 0 ? nb[dir] : c;
+    v0[dir] = f4[4 * v];
+    v2[dir] = f4[4 * v + 2];
+    v3[dir] = f4[4 * v + 3];
+  }
+  const uint32_t info = __float_as_uint(o3.w);
   uint32_t m = 0;
   if (info & CELL_PLANAR) {
     m = F_UNASSIGNED | ((info >> 8) << META_BIN_SHIFT);
-    const float nx = fc[c].normal[0], ny = fc[c].normal[1], nz = fc[c].normal[2];
-    const double du = static_cast<double>(fc[c].d);
+    const float nx = o2.y, ny = o2.z, nz = o2.w;
+    const double du = static_cast<double>(o3.x);
     const float nf = static_cast<float>(prm.n);
-    const float smx = fc[c].sum[0] / nf, smy = fc[c].sum[1] / nf, smz = fc[c].sum[2] / nf;  // own mean (for in-edges)
-    const double tol_self = static_cast<double>(fc[c].tol);
-    const int nb[4] = {cr >= 1 ? c - prm.nh : -1, cr + 1 < prm.nv ? c + prm.nh : -1, cc >= 1 ? c - 1 : -1,
-                       cc + 1 < prm.nh ? c + 1 : -1};
+    const float smx = o0.x / nf, smy = o0.y / nf, smz = o0.z / nf;  // own mean (for in-edges)
+    const double tol_self = static_cast<double>(o3.z);
 #pragma unroll
     for (int dir = 0; dir < 4; ++dir) {
-      const int v = nb[dir];
-      if (v < 0) continue;
-      const dpx_cell& cv = fc[v];
-      if (!(cv.info & CELL_PLANAR)) continue;
-      const float cosf_ = dot3(nx, ny, nz, cv.normal[0], cv.normal[1], cv.normal[2]);
+      if (nb[dir] < 0) continue;
+      if (!(__float_as_uint(v3[dir].w) & CELL_PLANAR)) continue;
+      const float vnx = v2[dir].y, vny = v2[dir].z, vnz = v2[dir].w;
+      const float cosf_ = dot3(nx, ny, nz, vnx, vny, vnz);
       if (!(static_cast<double>(cosf_) >= static_cast<double>(prm.min_cos))) continue;  // the cosine is symmetric
       // out-edge  c -> v : (n_c . mean_v + d_c)^2 <= tol_v
-      const float mx = cv.sum[0] / nf, my = cv.sum[1] / nf, mzv = cv.sum[2] / nf;  // mean_ = coord_sum_/nr_pts_
+      const float mx = v0[dir].x / nf, my = v0[dir].y / nf, mzv = v0[dir].z / nf;  // mean_ = coord_sum_/nr_pts_
       const double tt = static_cast<double>(dot3(nx, ny, nz, mx, my, mzv)) + du;
-      if (tt * tt <= static_cast<double>(cv.tol)) m |= (F_EDGE0 << dir);
+      if (tt * tt <= static_cast<double>(v3[dir].z)) m |= (F_EDGE0 << dir);
       // in-edge   v -> c : (n_v . mean_c + d_v)^2 <= tol_c
-      const double ti = static_cast<double>(dot3(cv.normal[0], cv.normal[1], cv.normal[2], smx, smy, smz)) + static_cast<double>(cv.d);
+      const double ti = static_cast<double>(dot3(vnx, vny, vnz, smx, smy, smz)) + static_cast<double>(v3[dir].x);
       if (ti * ti <= tol_self) m |= (F_INEDGE0 << dir);
     }
   }
   meta[gid] = m;
-  mse_c[gid] = fc[c].mse;  // compact copy for the region-growing kernel's seed search
+  mse_c[gid] = o3.y;  // compact copy for the region-growing kernel's seed search
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -76,11 +76,8 @@ struct CoreBufs {
 // never written with plain stores: the per-XCD L2s are not coherent with each other, atomics execute at the memory side,
 // and a plain store stays in the storing XCD's L2 as a dirty line whose later write-back would put the old value over an
 // atomic's result (seen as a lost union: one frame in ~100 under load).  Write-through (sc1) stores leave no such line.
-#ifndef DPX_CC_LOAD_SCOPE
-#define DPX_CC_LOAD_SCOPE __HIP_MEMORY_SCOPE_AGENT
-#endif
 __device__ __forceinline__ uint32_t cc_load(const uint32_t* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, DPX_CC_LOAD_SCOPE);
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void cc_store(uint32_t* p, uint32_t v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -103,15 +100,11 @@ __device__ __forceinline__ uint32_t cc_find(uint32_t* p, uint32_t x) {
     if (q == r) break;
     r = q;
   }
-#ifdef DPX_CC_SELF_ONLY
-  if (x != r && cc_load(p + x) > r) atomicMin(p + x, r);
-#else
   while (x != r) {  // compression
     const uint32_t nx = cc_load(p + x);
     if (nx > r) atomicMin(p + x, r);
     x = nx < x ? nx : r;
   }
-#endif
   return r;
 }
 __device__ __forceinline__ void cc_union(uint32_t* p, uint32_t a, uint32_t b) {
