@@ -19,9 +19,10 @@ from pathlib import Path
 
 import numpy as np
 
-# HIP maps streams onto at most GPU_MAX_HW_QUEUES hardware queues (default 4); the bench keeps 16 batches in flight so
-# that the latency-bound region-growing kernel of one batch overlaps the bandwidth/ALU-bound kernels of the others.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# HIP maps streams onto at most GPU_MAX_HW_QUEUES hardware queues (default 4); the bench keeps up to 20 batches in flight so
+# that the latency-bound region-growing kernels of one batch overlap the bandwidth/ALU-bound kernels of the others (two
+# streams that share a hardware queue run one after the other: 16 streams on 16 queues next to torch's own were slower than 14).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
@@ -49,10 +50,12 @@ def dist_env():
 # seed-list sort, tails, label expansion) fill the time: 1280x960 x 256: 101 k / 157 k / 199 k (211 k with the final sweep rounds) / 208 k / 185 k frames/s with
 # 2 / 4 / 8 / 12 / 16 batches in flight; 640x480 x 512: 0.78 M / 1.19 M / 1.48 M / 1.37 M with 2 / 4 / 8 / 16; 3840x2160 x 8:
 # 0.85 k / 1.6 k / 3.0 k (3.8 k with the final kernels) with 2 / 4 / 8 (8 in flight = the 64 frames of configs[4] on this one GPU).
-# synth4k64 = ALL 64 frames of configs[4] per step on one GPU (the noisiest frame of a batch sets the batch's time and a frame
-# holds one CU: 64-frame batches keep 256+ frames in flight): 5.8 k / 10.0 k / 12.8 k (15.8 k with the final kernels) frames/s with 2 / 4 / 8 batches in flight.
+# synth4k64 = ALL 64 frames of configs[4] per step on one GPU: bound by the chip (26.7 k frames/s with 8 or 12 batches in flight, 24 k with 16).
+# synth4k = one GPU's share of configs[4], 8 frames per step: bound by the latency of a batch's chain of launches (6.4 ms), so it
+# takes many batches in flight — 8.3 k / 11.3 k / 13.7 k / 14.7 k / 14.4 k frames/s with 8 / 12 / 16 / 20 / 24.  Steps cover several
+# rounds of the slots, or the fill and the drain of the pipeline are most of the timed region.
 BIG_WORKLOADS = {"synth1280": dict(batch=256, unique=8, steps=32, warmup=8, streams=8), "synth640": dict(batch=512, unique=16, steps=64, warmup=16, streams=8),
-                 "synth4k": dict(batch=8, unique=4, steps=24, warmup=8, streams=8), "synth4k64": dict(batch=64, unique=4, steps=24, warmup=8, streams=8)}
+                 "synth4k": dict(batch=8, unique=4, steps=160, warmup=40, streams=20), "synth4k64": dict(batch=64, unique=4, steps=48, warmup=16, streams=8)}
 
 
 def make_workload(name: str, batch: int, rank: int, part: int = 0, parts: int = 1, unique: int = 0):
