@@ -12,14 +12,18 @@
 // of a grow from seed s are the cores reachable from core(s) over the remaining one-way edges among the cores still alive
 // — and with no one-way edge leaving core(s), simply core(s), whatever happened before.  (Removing a reachable set never
 // splits a core: the unassigned set stays a union of whole cores, by induction.)  Hence:
-//   k_core_*    cores by parallel union-find over the symmetric edges, chip-wide; cells grouped by core (CSR);
-//   k_regsim    the SEQUENCE of grows, one wave per frame: which bin fires, its seed, the cores it takes, the histogram
-//               update — no BFS.  Up to 64 bins of one histogram level fire per round ("sweep rounds", as in
-//               dpx_regions2.h, where the argument for their order is spelled out), validated through per-bin claims;
+//   k_core_*    cores by parallel union-find over the symmetric edges: 32 x 32-cell tiles in LDS (k_core_tiles), then the
+//               edges across tile borders in memory (k_core_link), roots per cell and the (core, bin) pairs (k_core_flatten);
+//   k_pair_*, k_core_alloc, k_edge_scatter, k_bin_sort    pairs by core, one-way edges by core, seed lists by bin;
+//   k_regsim    the SEQUENCE of grows, one wave per frame (+ a helper wave that keeps the seed lists' windows in LDS filled):
+//               which bin fires, its seed, the cores it takes, the histogram update — no BFS.  Up to 64 bins of one
+//               histogram level fire per round ("sweep rounds", as in dpx_regions2.h, where the argument for their order is
+//               spelled out), validated through per-bin claims;
 //   k_cellgrow  per cell: the grow that took it + its in-edge bits in one word;
 //   k_order     the FIFO activation order of every grow that is a segment candidate, all grows in parallel (wave per
 //               grow; grows of up to 8 cells one LANE each), written to the queue ranges the sequence assigned;
-//   the tail (segment sums in queue order, f64 fits, labels_map_, plane merging) is k_regions2<0, ., 3>.
+//   k_seg_accum, k_seg_fit    segment sums in queue order and f64 fits, chip-wide;
+//   the rest of the tail (ordered ids, labels_map_, plane merging, final labels) is k_regions2<0, ., 5>.
 // Bit-exact with the cell-level kernels of dpx_regions2.h / the oracle on every record (tests, tools/fuzz_parity.py).
 #pragma once
 #include "dpx_regions2.h"
