@@ -51,11 +51,13 @@ def dist_env():
 # 2 / 4 / 8 / 12 / 16 batches in flight; 640x480 x 512: 0.78 M / 1.19 M / 1.48 M / 1.37 M with 2 / 4 / 8 / 16; 3840x2160 x 8:
 # 0.85 k / 1.6 k / 3.0 k (3.8 k with the final kernels) with 2 / 4 / 8 (8 in flight = the 64 frames of configs[4] on this one GPU).
 # synth4k64 = ALL 64 frames of configs[4] per step on one GPU: bound by the chip (26.7 k frames/s with 8 or 12 batches in flight, 24 k with 16).
-# synth4k = one GPU's share of configs[4], 8 frames per step: bound by the latency of a batch's chain of launches (6.4 ms), so it
-# takes many batches in flight — 8.3 k / 11.3 k / 13.7 k / 14.7 k / 14.4 k frames/s with 8 / 12 / 16 / 20 / 24.  Steps cover several
-# rounds of the slots, or the fill and the drain of the pipeline are most of the timed region.
+# synth4k = one GPU's share of configs[4], 8 frames per step.  One launch sequence per step (22 launches) is bound by the host:
+# 8.3 / 11.3 / 13.7 / 14.7 / 14.4 k frames/s with 8 / 12 / 16 / 20 / 24 steps in flight, the queues idle 72 % of the time
+# (tools/trace_busy.py).  With `group` steps per launch sequence (as the default workload does with 8): 21.3 k (20 x 2), 24.4 k
+# (16 x 4), 24.8 k (12 x 8) — next to synth4k64's chip-bound 26.7 k.  Steps cover several rounds of the slots, or the fill and the
+# drain of the pipeline are most of the timed region.
 BIG_WORKLOADS = {"synth1280": dict(batch=256, unique=8, steps=32, warmup=8, streams=8), "synth640": dict(batch=512, unique=16, steps=64, warmup=16, streams=8),
-                 "synth4k": dict(batch=8, unique=4, steps=160, warmup=40, streams=20), "synth4k64": dict(batch=64, unique=4, steps=48, warmup=16, streams=8)}
+                 "synth4k": dict(batch=8, unique=4, steps=384, warmup=96, streams=12, group=8), "synth4k64": dict(batch=64, unique=4, steps=48, warmup=16, streams=8)}
 
 
 def make_workload(name: str, batch: int, rank: int, part: int = 0, parts: int = 1, unique: int = 0):
@@ -187,7 +189,7 @@ def main():
     # `sustained` the same shape over 2000 steps.  (Until round 3 short runs took 16 x 5 because that shape divides 20 steps
     # into whole groups: a number shaped by the protocol, dropped.)
     S = args.streams if args.streams > 0 else (big["streams"] if big else 4)  # groups in flight (pipeline slots), one stream each
-    G = max(1, min(32, args.group)) if args.group > 0 else (1 if big else 8)
+    G = max(1, min(32, args.group)) if args.group > 0 else (big.get("group", 1) if big else 8)
     if big and args.inputs == 8:
         args.inputs = 2
     # The steps rotate over R distinct input batches (R divides the S*G output buffers, so buffer k always holds the
