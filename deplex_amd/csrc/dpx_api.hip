@@ -533,11 +533,8 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
   if (total > 0 && h->cores && !skip_r) {  // cores of the symmetric edges and their (core, bin) pairs (dpx_regions3.h), before the seed lists
     const dpx::CoreBufs cb = core_bufs(h);
     const int nbins = prm.hist_B * prm.hist_B;
-    const int n_init = std::max(prm.C, nbins);
-    const dim3 g_init(static_cast<unsigned>((n_init + 255) / 256), static_cast<unsigned>(batch));
     const int sort_wgs = std::max(4, std::min(std::min(64, nbins), 2048 / std::max(1, batch)));
     const dim3 tile_grid(static_cast<unsigned>(((prm.nh + dpx::kTile - 1) / dpx::kTile) * ((prm.nv + dpx::kTile - 1) / dpx::kTile)), static_cast<unsigned>(batch));
-    hipLaunchKernelGGL(dpx::k_core_init, g_init, dim3(256), 0, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_core_tiles, tile_grid, dim3(dpx::kTile * dpx::kTile), 0, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_core_link, tile_grid, dim3(64), 0, s, prm, cb);
     const dim3 prep_grid(static_cast<unsigned>((prm.C + dpx::kPrepT - 1) / dpx::kPrepT), static_cast<unsigned>(batch));

@@ -145,34 +145,6 @@ __device__ __forceinline__ uint32_t pair_slot(uint32_t* hkey, int logT, uint32_t
   }
 }
 
-// grid (ceil(max(C, bins) / 256), B), 256 threads: the per-cell and per-bin counters of the preparation start at zero
-// (write-through, like every store that a later launch's atomics must find in memory)
-__global__ __launch_bounds__(256) void k_core_init(Params prm, CoreBufs cb) {
-  const int frame = blockIdx.y;
-  const int i = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
-  const size_t fo = static_cast<size_t>(frame) * prm.C;
-  if (i < prm.C) {
-    cc_store(cb.csize + fo + i, 0u);
-    cc_store(cb.npairs + fo + i, 0u);
-    cc_store(cb.pfill + fo + i, 0u);
-    cc_store(cb.noe + fo + i, 0u);
-    cc_store(cb.oefill + fo + i, 0u);
-    cb.cgrow[fo + i] = 0u;  // (written by one wave of one later launch, read by the launch after it: plain)
-  }
-  const int nb = prm.hist_B * prm.hist_B;
-  if (i < nb) {
-    cc_store(cb.histg + static_cast<size_t>(frame) * nb + i, 0u);
-    cc_store(cb.pbcnt + static_cast<size_t>(frame) * nb + i, 0u);
-  }
-  if (i == 0) {
-    cc_store(cb.cursor + 4 * frame, 0u);
-    cc_store(cb.cursor + 4 * frame + 1, 0u);
-    cc_store(cb.cursor + 4 * frame + 2, 0u);
-    cc_store(cb.cursor + 4 * frame + 3, 0u);
-    for (int k = 0; k < 4; ++k) __hip_atomic_store(cb.order_task + 4 * frame + k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
 // ---- cores, first level: 32 x 32-cell tiles joined in LDS ---------------------------------------------------------------
 // A workgroup takes one tile, joins its cells along the symmetric edges with the same union-find in LDS (hooking by
 // compare-and-swap, parents always lower than children — local index order is cell index order inside a tile), and writes
@@ -186,7 +158,7 @@ __device__ __forceinline__ uint32_t lds_find(volatile uint32_t* lp, uint32_t x) 
     x = q;
   }
 }
-// grid (tiles across * tiles down, B), 1024 threads
+// grid (tiles across * tiles down, B), 1024 threads; also zeroes the counters of the later launches
 __global__ __launch_bounds__(kTile * kTile) void k_core_tiles(Params prm, CoreBufs cb) {
   __shared__ uint32_t lp[kTile * kTile];
   const int frame = blockIdx.y;
@@ -231,6 +203,25 @@ __global__ __launch_bounds__(kTile * kTile) void k_core_tiles(Params prm, CoreBu
   if (inside) {
     const uint32_t lr = planar ? lds_find(lp, static_cast<uint32_t>(t)) : static_cast<uint32_t>(t);
     cc_store(cb.parent + fo + c, static_cast<uint32_t>((by * kTile + static_cast<int>(lr >> 5)) * prm.nh + bx * kTile + static_cast<int>(lr & (kTile - 1))));
+    // the per-cell counters of the preparation start at zero (write-through, like every store that a later launch's
+    // atomics must find in memory)
+    cc_store(cb.csize + fo + c, 0u);
+    cc_store(cb.npairs + fo + c, 0u);
+    cc_store(cb.pfill + fo + c, 0u);
+    cc_store(cb.noe + fo + c, 0u);
+    cc_store(cb.oefill + fo + c, 0u);
+    cb.cgrow[fo + c] = 0u;  // (written by one wave of one later launch, read by the launch after it: plain)
+  }
+  if (blockIdx.x == 0) {  // and the frame's per-bin counters and cursors
+    const int nb = prm.hist_B * prm.hist_B;
+    for (int i = t; i < nb; i += kTile * kTile) {
+      cc_store(cb.histg + static_cast<size_t>(frame) * nb + i, 0u);
+      cc_store(cb.pbcnt + static_cast<size_t>(frame) * nb + i, 0u);
+    }
+    if (t < 4) {
+      cc_store(cb.cursor + 4 * frame + t, 0u);
+      __hip_atomic_store(cb.order_task + 4 * frame + t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -601,7 +592,7 @@ __global__ __launch_bounds__(64) void k_bin_scan(Params prm, CoreBufs cb) {
 // further load for a core of up to four bins (a core with one-way edges out: two pairs, first edge, number of edges).  Segments of up to kBinSortMax keys are sorted in LDS (all-ascending bitonic
 // network on exactly n keys, as in dpx_regions2.h's preparation), longer ones in place in global memory by the same
 // workgroup.
-constexpr int kBinSortT = 256, kBinSortMax = 4096;       // the core path's form: pairs per bin are few
+constexpr int kBinSortT = 256, kBinSortMax = 1024;       // the core path's form: pairs per bin are few (574 in the top bin of the noisiest 4K test frame); 8 KB of LDS, so that all of a batch's workgroups are resident at once
 constexpr int kCellSortT = 1024, kCellSortMax = 16384;   // the cell-level form: a clean frame has most of its cells in one bin
 // CELLS = the cell-level tiers' form: the sorted segment's cell ids go to `order` (cb.keys, cb.bin_off, cb.Cpad are all it reads).
 // `cap` = keys the launch's dynamic LDS holds (8 bytes each).
@@ -614,9 +605,57 @@ __global__ __launch_bounds__(CELLS ? kCellSortT : kBinSortT) void k_bin_sort(Par
   const uint32_t* bo = cb.bin_off + static_cast<size_t>(frame) * (nb + 1);
   extern __shared__ __align__(16) unsigned char sk_raw[];
   unsigned long long* sk = reinterpret_cast<unsigned long long*>(sk_raw);
-  for (int bin = blockIdx.x; bin < nb; bin += gridDim.x) {  // (a few workgroups per frame: most bins are empty)
+  const size_t fo = static_cast<size_t>(frame) * prm.C;
+  // a list entry of the core path from its sorted key (CELLS: the cell id into `order`)
+  auto emit = [&](int at, unsigned long long key) {
+    const uint32_t cell = static_cast<uint32_t>(key & kCellMask);
+    if constexpr (CELLS) {
+      order[fo + at] = cell;
+    } else {
+      const uint32_t r = cb.parent[fo + cell];
+      const uint32_t ps = cb.pstart[fo + r], np = cb.npairs[fo + r];
+      uint4 pr = make_uint4(0u, 0u, 0u, 0u);
+      const uint32_t* cp = cb.corepairs + fo + ps;
+      pr.x = cp[0];
+      if (np > 1) pr.y = cp[1];
+      if (np > 2) pr.z = cp[2];
+      if (np > 3) pr.w = cp[3];
+      const uint32_t ne = cb.noe[fo + r];
+      if (ne) {  // a core with one-way edges out: two pairs + where its edges are
+        pr.z = cb.oestart[fo + r];
+        pr.w = ne;
+      }
+      cb.lists[2 * (fo + at)] = make_uint4(cell | (ne ? kCoreOut : 0u), ps, np, cb.csize[fo + r]);
+      cb.lists[2 * (fo + at) + 1] = pr;
+    }
+  };
+  // Bins of at most 64 keys — most bins of a noisy frame — are a WAVE's work: the keys in registers, a bitonic network
+  // over the lanes, no LDS and no workgroup barrier; the waves of the launch take such bins independently.
+  {
+    const int lane = tid & 63, wid = tid >> 6, nwaves = kBinSortT >> 6;
+    for (int bin = static_cast<int>(blockIdx.x) * nwaves + wid; bin < nb; bin += static_cast<int>(gridDim.x) * nwaves) {
+      const int s0 = static_cast<int>(bo[bin]), n = static_cast<int>(bo[bin + 1]) - s0;
+      if (n <= 0 || n > 64) continue;
+      unsigned long long v = lane < n ? cb.keys[static_cast<size_t>(frame) * cb.Cpad + s0 + lane] : ~0ull;
+      if (n > 1) {
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+          for (int j = k >> 1; j >= 1; j >>= 1) {
+            const unsigned long long o = __shfl_xor(v, j);
+            const bool up = (lane & k) == 0;             // this block sorts ascending
+            const bool low = (lane & j) == 0;            // this lane keeps the smaller of the pair (in an ascending block)
+            const bool take_min = up == low;
+            v = take_min ? (o < v ? o : v) : (o > v ? o : v);
+          }
+        }
+      }
+      if (lane < n) emit(s0 + lane, v);
+    }
+  }
+  for (int bin = blockIdx.x; bin < nb; bin += gridDim.x) {  // the larger bins: the workgroup, keys in LDS
   const int s0 = static_cast<int>(bo[bin]), n = static_cast<int>(bo[bin + 1]) - s0;
-  if (n <= 0) continue;
+  if (n <= 64) continue;
   __syncthreads();  // (sk is reused)
   unsigned long long* g = cb.keys + static_cast<size_t>(frame) * cb.Cpad + s0;
   const bool in_lds = n <= kBinSortMax;
@@ -657,30 +696,7 @@ __global__ __launch_bounds__(CELLS ? kCellSortT : kBinSortT) void k_bin_sort(Par
       }
     }
   }
-  const size_t fo = static_cast<size_t>(frame) * prm.C;
-  for (int i = tid; i < n; i += kBinSortT) {
-    const unsigned long long key = in_lds ? sk[i] : __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t cell = static_cast<uint32_t>(key & kCellMask);
-    if constexpr (CELLS) {
-      order[fo + s0 + i] = cell;
-      continue;
-    }
-    const uint32_t r = cb.parent[fo + cell];
-    const uint32_t ps = cb.pstart[fo + r], np = cb.npairs[fo + r];
-    uint4 pr = make_uint4(0u, 0u, 0u, 0u);
-    const uint32_t* cp = cb.corepairs + fo + ps;
-    pr.x = cp[0];
-    if (np > 1) pr.y = cp[1];
-    if (np > 2) pr.z = cp[2];
-    if (np > 3) pr.w = cp[3];
-    const uint32_t ne = cb.noe[fo + r];
-    if (ne) {  // a core with one-way edges out: two pairs + where its edges are
-      pr.z = cb.oestart[fo + r];
-      pr.w = ne;
-    }
-    cb.lists[2 * (fo + s0 + i)] = make_uint4(cell | (ne ? kCoreOut : 0u), ps, np, cb.csize[fo + r]);
-    cb.lists[2 * (fo + s0 + i) + 1] = pr;
-  }
+  for (int i = tid; i < n; i += kBinSortT) emit(s0 + i, in_lds ? sk[i] : __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   }
 }
 
@@ -1441,7 +1457,7 @@ struct OrderBufs {
   const uint32_t* biglist;  // [B][pcap]
   const int* hdr;           // [B][48]
   uint32_t* queue;          // [B][C]
-  int* task;                // [B][4] task counters: waves' tasks, workgroups' tasks (+ k_seg_accum's two) (zeroed by k_core_init)
+  int* task;                // [B][4] task counters: waves' tasks, workgroups' tasks (+ k_seg_accum's two) (zeroed by k_core_tiles)
   unsigned long long* dbg;
   int pcap;
 };
