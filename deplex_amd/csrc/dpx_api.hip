@@ -406,16 +406,19 @@ void launch_binsort(dpx_handle h, const dpx::Params& prm, hipStream_t s) {
   if (!h->opt_sort_bitonic) {
     // counting sort over the bins, then every bin's segment sorted by (mse, cell) in LDS (dpx_regions3.h)
     const int nbins = prm.hist_B * prm.hist_B, B = prm.batch;
-    const dim3 cell_grid(static_cast<unsigned>((prm.C + 255) / 256), static_cast<unsigned>(B));
+    const dim3 cell_grid(static_cast<unsigned>((prm.C + dpx::kPrepT - 1) / dpx::kPrepT), static_cast<unsigned>(B));
     dpx::CoreBufs cb{};
     cb.keys = h->d_sort_keys; cb.bin_off = h->d_bin_off; cb.pbcnt = h->d_pbcnt; cb.Cpad = h->Cpad;
     (void)hipMemsetAsync(h->d_pbcnt, 0, static_cast<size_t>(B) * nbins * 4, s);
-    hipLaunchKernelGGL(dpx::k_cell_bincount, cell_grid, dim3(256), 0, s, prm, h->d_meta, h->d_pbcnt);
+    hipLaunchKernelGGL(dpx::k_cell_bincount, cell_grid, dim3(dpx::kPrepT), static_cast<size_t>(nbins) * 4, s, prm, h->d_meta, h->d_pbcnt);
     hipLaunchKernelGGL(dpx::k_bin_scan, dim3(static_cast<unsigned>(B)), dim3(64), 0, s, prm, cb);
-    hipLaunchKernelGGL(dpx::k_cell_scatter, cell_grid, dim3(256), 0, s, prm, h->d_meta, h->d_mse_c, h->d_pbcnt, h->d_bin_off, h->d_sort_keys, h->Cpad);
-    const int sort_wgs = std::max(4, std::min(std::min(64, nbins), 2048 / std::max(1, B)));
+    hipLaunchKernelGGL(dpx::k_cell_scatter, cell_grid, dim3(dpx::kPrepT), static_cast<size_t>(nbins) * 4, s, prm, h->d_meta, h->d_mse_c, h->d_pbcnt, h->d_bin_off, h->d_sort_keys, h->Cpad);
+    // the segments of up to kCellSortSmall keys: many small workgroups (8 KB of LDS each, waves for the smallest); the few
+    // beyond — a clean frame's one big bin — one 1024-thread workgroup per frame with LDS for the whole frame's cells
+    const int sort_wgs = std::max(4, std::min(std::min(64, nbins), 4096 / std::max(1, B)));
+    hipLaunchKernelGGL((dpx::k_bin_sort<true>), dim3(static_cast<unsigned>(std::min(sort_wgs, nbins)), static_cast<unsigned>(B)), dim3(256), static_cast<size_t>(dpx::kCellSortSmall) * 8, s, prm, cb, h->d_order, dpx::kCellSortSmall, 0);
     const int cap = std::max(64, std::min(prm.C, dpx::kCellSortMax));
-    hipLaunchKernelGGL((dpx::k_bin_sort<true>), dim3(static_cast<unsigned>(std::min(sort_wgs, nbins)), static_cast<unsigned>(B)), dim3(dpx::kCellSortT), static_cast<size_t>(cap) * 8, s, prm, cb, h->d_order, cap);
+    hipLaunchKernelGGL((dpx::k_bin_sort<true>), dim3(1, static_cast<unsigned>(B)), dim3(dpx::kCellSortT), static_cast<size_t>(cap) * 8, s, prm, cb, h->d_order, cap, dpx::kCellSortSmall);
     return;
   }
   const int Cpad = h->Cpad, B = prm.batch;
@@ -544,7 +547,7 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
     hipLaunchKernelGGL(dpx::k_bin_scan, dim3(static_cast<unsigned>(batch)), dim3(64), 0, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_pair_scatter, prep_grid, dim3(dpx::kPrepT), static_cast<size_t>(nbins) * 8, s, prm, cb);
     hipLaunchKernelGGL(dpx::k_edge_scatter, cell_grid, dim3(256), 0, s, prm, cb);
-    hipLaunchKernelGGL((dpx::k_bin_sort<false>), dim3(static_cast<unsigned>(std::min(sort_wgs, nbins)), static_cast<unsigned>(batch)), dim3(dpx::kBinSortT), static_cast<size_t>(dpx::kBinSortMax) * 8, s, prm, cb, static_cast<uint32_t*>(nullptr), dpx::kBinSortMax);
+    hipLaunchKernelGGL((dpx::k_bin_sort<false>), dim3(static_cast<unsigned>(std::min(sort_wgs, nbins)), static_cast<unsigned>(batch)), dim3(dpx::kBinSortT), static_cast<size_t>(dpx::kBinSortMax) * 8, s, prm, cb, static_cast<uint32_t*>(nullptr), dpx::kBinSortMax, 0);
   }
   if (total > 0 && (h->regions_tier == 1 || h->regions_tier == 0) && !h->cores && !skip_r) launch_binsort(h, prm, s);
   if (prof) DPX_HIP(hipEventRecord(ev[3], s));

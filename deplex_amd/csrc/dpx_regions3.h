@@ -594,11 +594,13 @@ __global__ __launch_bounds__(64) void k_bin_scan(Params prm, CoreBufs cb) {
 // workgroup.
 constexpr int kBinSortT = 256, kBinSortMax = 1024;       // the core path's form: pairs per bin are few (574 in the top bin of the noisiest 4K test frame); 8 KB of LDS, so that all of a batch's workgroups are resident at once
 constexpr int kCellSortT = 1024, kCellSortMax = 16384;   // the cell-level form: a clean frame has most of its cells in one bin
+constexpr int kCellSortSmall = 1024;                     // segments up to here: the launch of many small workgroups
 // CELLS = the cell-level tiers' form: the sorted segment's cell ids go to `order` (cb.keys, cb.bin_off, cb.Cpad are all it reads).
 // `cap` = keys the launch's dynamic LDS holds (8 bytes each).
+// The launch takes the segments of more than `above` keys (0: all; then segments of up to 64 keys are a wave's work).
 template <bool CELLS>
-__global__ __launch_bounds__(CELLS ? kCellSortT : kBinSortT) void k_bin_sort(Params prm, CoreBufs cb, uint32_t* __restrict__ order, int cap) {
-  constexpr int kBinSortT = CELLS ? kCellSortT : dpx::kBinSortT;  // (this launch's workgroup size)
+__global__ __launch_bounds__(CELLS ? kCellSortT : kBinSortT) void k_bin_sort(Params prm, CoreBufs cb, uint32_t* __restrict__ order, int cap, int above) {
+  const int kBinSortT = static_cast<int>(blockDim.x);  // (this launch's workgroup size: up to the bound above)
   const int kBinSortMax = cap;
   const int frame = blockIdx.y, tid = threadIdx.x;
   const int nb = prm.hist_B * prm.hist_B;
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(CELLS ? kCellSortT : kBinSortT) void k_bin_sort(Par
   };
   // Bins of at most 64 keys — most bins of a noisy frame — are a WAVE's work: the keys in registers, a bitonic network
   // over the lanes, no LDS and no workgroup barrier; the waves of the launch take such bins independently.
-  {
+  if (above == 0) {
     const int lane = tid & 63, wid = tid >> 6, nwaves = kBinSortT >> 6;
     for (int bin = static_cast<int>(blockIdx.x) * nwaves + wid; bin < nb; bin += static_cast<int>(gridDim.x) * nwaves) {
       const int s0 = static_cast<int>(bo[bin]), n = static_cast<int>(bo[bin + 1]) - s0;
@@ -655,7 +657,7 @@ __global__ __launch_bounds__(CELLS ? kCellSortT : kBinSortT) void k_bin_sort(Par
   }
   for (int bin = blockIdx.x; bin < nb; bin += gridDim.x) {  // the larger bins: the workgroup, keys in LDS
   const int s0 = static_cast<int>(bo[bin]), n = static_cast<int>(bo[bin + 1]) - s0;
-  if (n <= 64) continue;
+  if (n <= 64 || n <= above || (CELLS && above == 0 && n > kBinSortMax)) continue;  // (CELLS: the segments beyond this launch's LDS are the next launch's)
   __syncthreads();  // (sk is reused)
   unsigned long long* g = cb.keys + static_cast<size_t>(frame) * cb.Cpad + s0;
   const bool in_lds = n <= kBinSortMax;
@@ -704,39 +706,52 @@ __global__ __launch_bounds__(CELLS ? kCellSortT : kBinSortT) void k_bin_sort(Par
 // k_cell_bincount: cells per bin; k_bin_scan: segment offsets; k_cell_scatter: every planar cell's (mse key << 19 | cell) into
 // its bin's segment; k_bin_sort_cells: each segment sorted, cell ids written to order[B][C].  Replaces the frame-wide bitonic
 // network of dpx_binsort.h (O(log^2 C) chip-wide passes over Cpad slots for keys whose top field is one of a few hundred bins).
-__global__ __launch_bounds__(256) void k_cell_bincount(Params prm, const uint32_t* __restrict__ meta, uint32_t* __restrict__ pbcnt) {
+// Both launches: grid (ceil(C / 1024), B), 1024 threads, LDS per-bin counters — a clean frame has 10 000 cells in ONE bin, and
+// one atomic per cell (or per wave) on that bin's counter is served one at a time at the memory side.
+__global__ __launch_bounds__(kPrepT) void k_cell_bincount(Params prm, const uint32_t* __restrict__ meta, uint32_t* __restrict__ pbcnt) {
+  extern __shared__ uint32_t s_bins[];
   const int frame = blockIdx.y;
-  const int c = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
+  const int c = static_cast<int>(blockIdx.x) * kPrepT + threadIdx.x;
   const int nb = prm.hist_B * prm.hist_B;
-  const int lane = threadIdx.x & 63;
-  int bin = -1;
+  for (int b = threadIdx.x; b < nb; b += kPrepT) s_bins[b] = 0u;
+  __syncthreads();
   if (c < prm.C) {
     const uint32_t m = meta[static_cast<size_t>(frame) * prm.C + c];
     const int bn = static_cast<int>(m >> META_BIN_SHIFT);
-    if ((m & F_UNASSIGNED) && bn >= 1 && bn - 1 < nb) bin = bn - 1;
+    if ((m & F_UNASSIGNED) && bn >= 1 && bn - 1 < nb) atomicAdd(&s_bins[bn - 1], 1u);
   }
-  unsigned long long todo = __ballot(bin >= 0);  // neighbouring cells mostly share their bin: one atomic per distinct bin of the wave
-  while (todo) {
-    const int l = static_cast<int>(__builtin_ctzll(todo));
-    const int b0 = __builtin_amdgcn_readlane(bin, l);
-    const unsigned long long same = __ballot(bin == b0) & todo;
-    if (lane == l) atomicAdd(pbcnt + static_cast<size_t>(frame) * nb + b0, static_cast<uint32_t>(__popcll(same)));
-    todo &= ~same;
-  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nb; b += kPrepT)
+    if (s_bins[b]) atomicAdd(pbcnt + static_cast<size_t>(frame) * nb + b, s_bins[b]);
 }
-__global__ __launch_bounds__(256) void k_cell_scatter(Params prm, const uint32_t* __restrict__ meta, const float* __restrict__ mse_c,
-                                                      uint32_t* __restrict__ pbcnt, const uint32_t* __restrict__ bin_off,
-                                                      unsigned long long* __restrict__ keys, int Cpad) {
+__global__ __launch_bounds__(kPrepT) void k_cell_scatter(Params prm, const uint32_t* __restrict__ meta, const float* __restrict__ mse_c,
+                                                         uint32_t* __restrict__ pbcnt, const uint32_t* __restrict__ bin_off,
+                                                         unsigned long long* __restrict__ keys, int Cpad) {
+  extern __shared__ uint32_t s_bins[];  // cells of the workgroup per bin -> first slot of theirs in the bin's segment
   const int frame = blockIdx.y;
-  const int c = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
-  if (c >= prm.C) return;
+  const int c = static_cast<int>(blockIdx.x) * kPrepT + threadIdx.x;
   const int nb = prm.hist_B * prm.hist_B;
   const size_t fo = static_cast<size_t>(frame) * prm.C;
-  const uint32_t m = meta[fo + c];
-  const int bn = static_cast<int>(m >> META_BIN_SHIFT);
-  if (!((m & F_UNASSIGNED) && bn >= 1 && bn - 1 < nb)) return;
-  const uint32_t at = bin_off[static_cast<size_t>(frame) * (nb + 1) + bn - 1] + atomicAdd(pbcnt + static_cast<size_t>(frame) * nb + bn - 1, 1u);
-  keys[static_cast<size_t>(frame) * Cpad + at] = (static_cast<unsigned long long>(sort_mse_key(mse_c[fo + c])) << kCellBits) | static_cast<unsigned long long>(c);
+  for (int b = threadIdx.x; b < nb; b += kPrepT) s_bins[b] = 0u;
+  __syncthreads();
+  int bin = -1;
+  uint32_t rank = 0u;
+  if (c < prm.C) {
+    const uint32_t m = meta[fo + c];
+    const int bn = static_cast<int>(m >> META_BIN_SHIFT);
+    if ((m & F_UNASSIGNED) && bn >= 1 && bn - 1 < nb) {
+      bin = bn - 1;
+      rank = atomicAdd(&s_bins[bin], 1u);
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nb; b += kPrepT)
+    if (s_bins[b]) s_bins[b] = atomicAdd(pbcnt + static_cast<size_t>(frame) * nb + b, s_bins[b]);
+  __syncthreads();
+  if (bin >= 0) {
+    const uint32_t at = bin_off[static_cast<size_t>(frame) * (nb + 1) + bin] + s_bins[bin] + rank;
+    keys[static_cast<size_t>(frame) * Cpad + at] = (static_cast<unsigned long long>(sort_mse_key(mse_c[fo + c])) << kCellBits) | static_cast<unsigned long long>(c);
+  }
 }
 
 // ---- the sequence of grows --------------------------------------------------------------------------------------------
