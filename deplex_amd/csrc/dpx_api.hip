@@ -612,6 +612,7 @@ int stage_rest(dpx_handle h, const SubBatch* subs, int nsub, int per_sub, bool d
       tb.cells = h->d_cells; tb.queue = h->d_gqueue; tb.cand_grow = reinterpret_cast<const uint4*>(h->d_cand_grow); tb.biglist = h->d_biglist;
       tb.hdr = reinterpret_cast<const int*>(h->d_lds_img); tb.cand = h->d_cand; tb.candfit = h->d_candfit; tb.task = h->d_order_task; tb.pcap = h->pcap;
       rx.candfit = h->d_candfit;
+      rx.biglist = h->d_biglist;
       hipLaunchKernelGGL((dpx::k_seg_accum<true>), dim3(per_frame_huge, batch), dim3(dpx::kAccWaves * 64), 0, s, prm, tb);
       CHK("k_seg_accum<huge>");
       const int per_frame_acc = std::max(1, std::min(32, 2048 / std::max(1, batch)));

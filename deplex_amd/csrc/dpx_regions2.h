@@ -189,6 +189,7 @@ struct Regions2Extra {
   unsigned long long* res;  // diagnostic (DPX_RESIDENCY=1): [B][4] shader-clock lifetime of the frame's workgroup in launch 1, 2, 3
   int32_t* labels_out[kMaxGroup];   // non-null: the tail also expands the cell labels to the pixel label map (fused K6);
   int frames_per_out;       // frame f writes to labels_out[f / frames_per_out] (grouped submissions have one buffer each)
+  const uint32_t* biglist;  // PHASE 5: [B][pcap] the candidates of 1 024 cells and more, listed from the end (dpx_regions3.h)
   const float* candfit;     // PHASE 5: [B][pcap][12] the candidate segments' fits (dpx_regions3.h k_seg_fit): mean, normal, d, mse, score, ok
 };
 

@@ -780,7 +780,10 @@ constexpr int kHugeMin = 1024;
 #define DPX_S3_WIN 8
 #endif
 constexpr int kWin = DPX_S3_WIN;  // seed-list entries per bin kept in LDS
-constexpr int kScan = 4;         // of which the sequence reads so many at a time
+#ifndef DPX_S3_SCAN
+#define DPX_S3_SCAN 4
+#endif
+constexpr int kScan = DPX_S3_SCAN;  // of which the sequence reads so many at a time
 constexpr int kEdgePre = 4;  // one-way edges of an event's core fetched ahead of its turn
 constexpr int kWideLds = 64; // cores of an irregular grow listed in LDS (more: in global memory)
 
@@ -1099,7 +1102,10 @@ __global__ __launch_bounds__(128) void k_regsim(Params prm, SimBufs sb) {
             e = x[k];
             adv = k;
           }
-        need = !(ok[0] || ok[1] || ok[2] || ok[3]);
+        bool any_ok = false;
+#pragma unroll
+        for (int k = 0; k < kScan; ++k) any_ok = any_ok || ok[k];
+        need = !any_ok;
         pos += adv;
         ask = need && pos >= whi;
       }
