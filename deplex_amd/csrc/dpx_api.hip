@@ -1146,10 +1146,10 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
   }
   if (h->cores) {
     const size_t T = static_cast<size_t>(h->core_T);
-    A(dev_alloc(&h->d_core, B * (16 * C + 2 * T + 2 * static_cast<size_t>(nb) + 8)));
+    A(dev_alloc(&h->d_core, B * (16 * C + 2 * T + 2 * static_cast<size_t>(nb) + 2 * dpx::kCtr) + 32));
     A(dev_alloc(&h->d_candfit, B * static_cast<size_t>(h->pcap) * 12));
     A(dev_alloc(&h->d_oedges, B * 4 * C));
-    A(dev_alloc(&h->d_crec, B * C));  // (+8: cursors [4], order task counters [2])
+    A(dev_alloc(&h->d_crec, B * C));
     A(dev_alloc(&h->d_hbest, B * T));
     A(dev_alloc(&h->d_lists, B * C * 2));
     if (rc == DPX_OK) {
@@ -1158,7 +1158,8 @@ static int create_handle(const dpx_config* cfg, int32_t image_height, int32_t im
       take(h->d_parent, C); take(h->d_csize, C); take(h->d_npairs, C); take(h->d_pstart, C); take(h->d_pfill, C); take(h->d_noe, C);
       take(h->d_oestart, C); take(h->d_oefill, C); take(h->d_corepairs, C); take(h->d_cgrow, C); take(h->d_cellq, C); take(h->d_worklist, 3 * C);
       take(h->d_biglist, C); take(h->d_hslots, C); take(h->d_hkey, T); take(h->d_hcnt, T); take(h->d_histg, static_cast<size_t>(nb)); take(h->d_pbcnt, static_cast<size_t>(nb));
-      take(h->d_ccursor, 4);
+      q = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(q) + 127u) & ~static_cast<uintptr_t>(127u));  // (a 128-byte line per frame and counter set)
+      take(h->d_ccursor, dpx::kCtr);
       h->d_order_task = reinterpret_cast<int*>(q);
       // the pair table starts empty; every call leaves it empty again (k_pair_scatter)
       if (hipMemset(h->d_hkey, 0xFF, B * T * 4) != hipSuccess || hipMemset(h->d_hcnt, 0, B * T * 4) != hipSuccess ||
@@ -1568,7 +1569,7 @@ int64_t dpx_debug_read_cores(dpx_handle h, int32_t which, int32_t frame, void* o
     case 5: src = h->d_lists + f * C * 2; bytes = C * 32; break;
     case 6: src = h->d_bin_off + f * (nb + 1); bytes = (nb + 1) * 4; break;
     case 7: src = h->d_histg + f * nb; bytes = nb * 4; break;
-    case 8: src = h->d_ccursor + f * 4; bytes = 16; break;
+    case 8: src = h->d_ccursor + f * dpx::kCtr; bytes = 16; break;
     case 9: src = reinterpret_cast<const int*>(h->d_lds_img) + f * 48; bytes = 192; break;
     case 10: src = h->d_cand_grow + f * static_cast<size_t>(h->pcap) * 4; bytes = static_cast<size_t>(h->pcap) * 16; break;
     case 11: src = h->d_gqueue + f * C; bytes = C * 4; break;

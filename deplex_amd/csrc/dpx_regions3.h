@@ -37,6 +37,10 @@ constexpr uint32_t kCellMask = (1u << kCellBits) - 1u;
 constexpr int kPairBinBits = 13;               // bins < 2^13 (dpx_binsort.h)
 constexpr uint32_t kPairBinMask = (1u << kPairBinBits) - 1u;
 constexpr uint32_t kPairEmpty = 0xFFFFFFFFu;
+// Words between two frames' counters (cursor[], order_task[]): a 128-byte line each.  Atomics on one LINE are served one after the
+// other at the memory side (tools/ubench/atomic_same.hip: 11.4 ns on one word, 5.7 ns over the 32 words of a line, 0.1 ns on
+// lines of their own): with four words per frame, eight frames' counters shared a line.
+constexpr int kCtr = 32;
 constexpr int kItemMax = 8;  // cores of up to this many PAIRS are handled inside a sweep round (one item per pair)
 
 // What the sequence of grows needs to know about a frame is proportional to its (core, bin) PAIRS, not its cells:
@@ -70,9 +74,9 @@ struct CoreBufs {
   uint32_t* bin_off;      // [B][nb + 1] first slot of every bin's segment in keys / lists
   uint4* lists;           // [B][C][2] the seed lists (k_bin_sort)
   uint32_t* cgrow;        // [B][C]   indexed by core ID: grow index + 1 (k_regsim)
-  uint32_t* cursor;       // [B][4]   allocation cursors of corepairs / oedges, planar cells of the frame
+  uint32_t* cursor;       // [B][kCtr] (4 used) allocation cursors of corepairs / oedges, planar cells of the frame
   uint32_t* cellq;        // [B][C]   k_cellgrow: (grow + 1) << 4 | in-edge bits
-  int* order_task;        // [B][4]   task counters of k_order and k_seg_accum
+  int* order_task;        // [B][kCtr] (4 used) task counters of k_order and k_seg_accum
   int T, logT, Cpad;
 };
 
@@ -219,8 +223,8 @@ __global__ __launch_bounds__(kTile * kTile) void k_core_tiles(Params prm, CoreBu
       cc_store(cb.pbcnt + static_cast<size_t>(frame) * nb + i, 0u);
     }
     if (t < 4) {
-      cc_store(cb.cursor + 4 * frame + t, 0u);
-      __hip_atomic_store(cb.order_task + 4 * frame + t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      cc_store(cb.cursor + kCtr * frame + t, 0u);
+      __hip_atomic_store(cb.order_task + kCtr * frame + t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -416,8 +420,8 @@ __global__ __launch_bounds__(kPrepT) void k_core_flatten(Params prm, CoreBufs cb
   woff = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(woff)));
   __syncthreads();
   if (tid == 0) {
-    if (s_misc[0]) atomicAdd(cb.cursor + 4 * frame + 2, s_misc[0]);
-    if (s_misc[1]) s_misc[2] = atomicAdd(cb.cursor + 4 * frame + 3, s_misc[1]);
+    if (s_misc[0]) atomicAdd(cb.cursor + kCtr * frame + 2, s_misc[0]);
+    if (s_misc[1]) s_misc[2] = atomicAdd(cb.cursor + kCtr * frame + 3, s_misc[1]);
   }
   __syncthreads();
   const uint32_t base = s_misc[2] + woff;
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(kPrepT) void k_core_flatten(Params prm, CoreBufs cb
 __global__ __launch_bounds__(kPrepT) void k_pair_count(Params prm, CoreBufs cb) {
   extern __shared__ uint32_t s_bins[];
   const int frame = blockIdx.y;
-  const int npair = static_cast<int>(cb.cursor[4 * frame + 3]);
+  const int npair = static_cast<int>(cb.cursor[kCtr * frame + 3]);
   if (static_cast<int>(blockIdx.x) * kPrepT >= npair) return;  // (the whole workgroup)
   const int nb = prm.hist_B * prm.hist_B;
   for (int b = threadIdx.x; b < nb; b += kPrepT) s_bins[b] = 0u;
@@ -479,8 +483,8 @@ __global__ __launch_bounds__(kPrepT) void k_core_alloc(Params prm, CoreBufs cb) 
       tp += a;
       te += b;
     }
-    s_base[0] = tp ? atomicAdd(cb.cursor + 4 * frame, tp) : 0u;
-    s_base[1] = te ? atomicAdd(cb.cursor + 4 * frame + 1, te) : 0u;
+    s_base[0] = tp ? atomicAdd(cb.cursor + kCtr * frame, tp) : 0u;
+    s_base[1] = te ? atomicAdd(cb.cursor + kCtr * frame + 1, te) : 0u;
   }
   __syncthreads();
   if (!root) return;
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(kPrepT) void k_core_alloc(Params prm, CoreBufs cb) 
 __global__ __launch_bounds__(kPrepT) void k_pair_scatter(Params prm, CoreBufs cb) {
   extern __shared__ uint32_t s_bins[];  // [bins] pairs of the workgroup -> first slot; [bins] their cells
   const int frame = blockIdx.y;
-  const int npair = static_cast<int>(cb.cursor[4 * frame + 3]);
+  const int npair = static_cast<int>(cb.cursor[kCtr * frame + 3]);
   if (static_cast<int>(blockIdx.x) * kPrepT >= npair) return;  // (the whole workgroup)
   const int nb = prm.hist_B * prm.hist_B;
   uint32_t* s_cnt = s_bins;
@@ -762,7 +766,7 @@ struct SimBufs {
   const uint32_t* corepairs;          // [B][C]
   const uint4* oedges;                // [B][4C]
   const uint2* crec;                  // [B][C]
-  const uint32_t* cursor;             // [B][4]: pairs, one-way edges, planar cells of the frame
+  const uint32_t* cursor;             // [B][kCtr]: pairs, one-way edges, planar cells of the frame
   uint32_t* cgrow;                    // [B][C]  by core ID: grow + 1
   uint32_t* worklist;                 // [B][3C] irregular grows: IDs of the cores taken [C], cores still to expand [C][2]
   uint4* cand_grow;                   // [B][pcap]  grow index, queue range [y, z), seed | kCandWide
@@ -879,7 +883,7 @@ __global__ __launch_bounds__(128) void k_regsim(Params prm, SimBufs sb) {
       cursor[b] = static_cast<int>(s1);
       bclaim[b] = 0xFFFFFFFFu;
     }
-    const int npair_total = static_cast<int>(sb.cursor[4 * frame]);
+    const int npair_total = static_cast<int>(sb.cursor[kCtr * frame]);
     for (int w = lane; w < (npair_total + 31) / 32 + 1; w += 64) cbits[w] = 0xFFFFFFFFu;
   }
   wave_sync();
@@ -967,7 +971,7 @@ __global__ __launch_bounds__(128) void k_regsim(Params prm, SimBufs sb) {
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) *static_cast<volatile int*>(hdr + 11) = rq_head;
   };
-  const int planar_total = static_cast<int>(sb.cursor[4 * frame + 2]);
+  const int planar_total = static_cast<int>(sb.cursor[kCtr * frame + 2]);
   auto alive = [&](uint32_t id) { return ((cbits[id >> 5] >> (id & 31u)) & 1u) != 0u; };
   if (DBG) t_setup = static_cast<unsigned long long>(__builtin_amdgcn_s_memtime()) - t_start;
 
@@ -1446,7 +1450,7 @@ __global__ __launch_bounds__(128) void k_regsim(Params prm, SimBufs sb) {
     d[11] = n_rounds; d[13] = static_cast<unsigned long long>(ngrow); d[14] = static_cast<unsigned long long>(ncand);
     d[15] = static_cast<unsigned long long>(tail); d[19] = n_refill; d[24] = static_cast<unsigned long long>(hdr[13]); d[25] = static_cast<unsigned long long>(static_cast<uint32_t>(hdr[14])); d[26] = static_cast<unsigned long long>(hdr[15]); d[21] = n_wide; d[22] = n_skip; d[23] = n_irreg; d[28] = n_multi;
     d[3] = a_ev; d[4] = a_seed; d[5] = a_items; d[6] = a_walk; d[7] = a_commit; d[8] = a_wide;
-    d[29] = static_cast<unsigned long long>(sb.cursor[4 * frame]); d[30] = static_cast<unsigned long long>(nbig) | (static_cast<unsigned long long>(nhuge) << 32);
+    d[29] = static_cast<unsigned long long>(sb.cursor[kCtr * frame]); d[30] = static_cast<unsigned long long>(nbig) | (static_cast<unsigned long long>(nhuge) << 32);
   }
 }
 
@@ -1478,7 +1482,7 @@ struct OrderBufs {
   const uint32_t* biglist;  // [B][pcap]
   const int* hdr;           // [B][48]
   uint32_t* queue;          // [B][C]
-  int* task;                // [B][4] task counters: waves' tasks, workgroups' tasks (+ k_seg_accum's two) (zeroed by k_core_tiles)
+  int* task;                // [B][kCtr] task counters: waves' tasks, workgroups' tasks (+ k_seg_accum's two) (zeroed by k_core_tiles)
   unsigned long long* dbg;
   int pcap;
 };
@@ -1531,7 +1535,7 @@ __global__ __launch_bounds__((HUGE ? kHugeWaves : kOrderWaves) * 64) void k_orde
     constexpr uint32_t kRingMask = kHugeRing - 1u;
     const uint32_t notme = ~(1u << opp) & 0xFu;
     for (int guard = 0; guard <= nhuge; ++guard) {
-      if (tid == 0) ctl[0] = atomicAdd(ob.task + 4 * frame + 1, 1);
+      if (tid == 0) ctl[0] = atomicAdd(ob.task + kCtr * frame + 1, 1);
       for (int i = tid; i < kHugeHash; i += kOrderWaves * 64) bmap[i] = 0xFFFFFFFFu;
       __syncthreads();
       const int t = ctl[0];
@@ -1621,7 +1625,7 @@ __global__ __launch_bounds__((HUGE ? kHugeWaves : kOrderWaves) * 64) void k_orde
   }
   for (int guard = 0; guard <= ntasks; ++guard) {  // (every task loop is bounded: a wave takes each task at most once)
     int t = 0;
-    if (lane == 0) t = atomicAdd(ob.task + 4 * frame, 1);
+    if (lane == 0) t = atomicAdd(ob.task + kCtr * frame, 1);
     t = __builtin_amdgcn_readfirstlane(t);
     if (t >= ntasks) break;
     if (t < nbig) {
@@ -1751,7 +1755,7 @@ struct TailBufs {
   const int* hdr;          // [B][48]
   float* cand;             // [B][pcap][12] sums(9), n_pts, grow index, (accepted id: the tail launch)
   float* candfit;          // [B][pcap][12] mean(3), normal(3), d, mse, score, ok
-  int* task;               // [B][4]: 2 = segments of k_seg_accum<false>, 3 = of k_seg_accum<true>
+  int* task;               // [B][kCtr]: 2 = segments of k_seg_accum<false>, 3 = of k_seg_accum<true>
   int pcap;
 };
 constexpr int kAccWaves = 4, kAccStage = 64, kAccChunk = 4;
@@ -1777,7 +1781,7 @@ __global__ __launch_bounds__(kAccWaves * 64) void k_seg_accum(Params prm, TailBu
     for (int guard = 0; guard <= ncand; ++guard) {  // (a wave can take at most every segment once)
       // (kAccChunk segments per pull: the frame's counter serves its atomics one after the other, ~100 ns each)
       int c0 = 0;
-      if (lane == 0) c0 = atomicAdd(tb.task + 4 * frame + 2, kAccChunk);
+      if (lane == 0) c0 = atomicAdd(tb.task + kCtr * frame + 2, kAccChunk);
       c0 = __builtin_amdgcn_readfirstlane(c0);
       if (c0 >= ncand) break;
       const int c1 = c0 + kAccChunk < ncand ? c0 + kAccChunk : ncand;
@@ -1840,7 +1844,7 @@ __global__ __launch_bounds__(kAccWaves * 64) void k_seg_accum(Params prm, TailBu
     const uint32_t* biglist = tb.biglist + static_cast<size_t>(frame) * tb.pcap;
     for (int guard = 0; guard <= nhuge; ++guard) {
       __syncthreads();
-      if (tid == 0) s_task = atomicAdd(tb.task + 4 * frame + 3, 1);
+      if (tid == 0) s_task = atomicAdd(tb.task + kCtr * frame + 3, 1);
       __syncthreads();
       const int t = s_task;
       if (t >= nhuge) break;
