@@ -599,6 +599,7 @@ __global__ __launch_bounds__(64) void k_bin_scan(Params prm, CoreBufs cb) {
 constexpr int kBinSortT = 256, kBinSortMax = 1024;       // the core path's form: pairs per bin are few (574 in the top bin of the noisiest 4K test frame); 8 KB of LDS, so that all of a batch's workgroups are resident at once
 constexpr int kCellSortT = 1024, kCellSortMax = 16384;   // the cell-level form: a clean frame has most of its cells in one bin
 constexpr int kCellSortSmall = 1024;                     // segments up to here: the launch of many small workgroups
+constexpr int kBinListMax = 1024;                        // bins of more than 64 keys a launch can list (LDS)
 // CELLS = the cell-level tiers' form: the sorted segment's cell ids go to `order` (cb.keys, cb.bin_off, cb.Cpad are all it reads).
 // `cap` = keys the launch's dynamic LDS holds (8 bytes each).
 // The launch takes the segments of more than `above` keys (0: all; then segments of up to 64 keys are a wave's work).
@@ -659,9 +660,29 @@ __global__ __launch_bounds__(CELLS ? kCellSortT : kBinSortT) void k_bin_sort(Par
       if (lane < n) emit(s0 + lane, v);
     }
   }
-  for (int bin = blockIdx.x; bin < nb; bin += gridDim.x) {  // the larger bins: the workgroup, keys in LDS
+  // the larger bins: the workgroup, keys in LDS.  Which bins those are is found by all threads at once (a loop over the
+  // frame's bins with two dependent loads each, just to skip most of them, was most of this launch's time)
+  __shared__ int s_big[kBinListMax];
+  __shared__ int s_nbig;
+  if (tid == 0) s_nbig = 0;
+  __syncthreads();
+  for (int b = tid; b < nb; b += kBinSortT) {
+    const int n = static_cast<int>(bo[b + 1]) - static_cast<int>(bo[b]);
+    // (CELLS: the segments beyond this launch's LDS are the next launch's)
+    if (static_cast<unsigned>(b) % gridDim.x == blockIdx.x && n > 64 && n > above && !(CELLS && above == 0 && n > kBinSortMax)) {  // (this workgroup's bins: every gridDim.x-th)
+      const int k = atomicAdd(&s_nbig, 1);
+      if (k < kBinListMax) s_big[k] = b;
+    }
+  }
+  __syncthreads();
+  const int nbig_bins = s_nbig;
+  // (more listed bins than the list holds cannot happen for C < 2^19 cells and > 64 keys each x kBinListMax; if it did, the
+  // plain loop over the workgroup's bins takes over)
+  const bool listed = nbig_bins <= kBinListMax;
+  for (int it = 0; it < (listed ? nbig_bins : (nb - static_cast<int>(blockIdx.x) + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x)); ++it) {
+  const int bin = listed ? s_big[it] : static_cast<int>(blockIdx.x) + it * static_cast<int>(gridDim.x);
   const int s0 = static_cast<int>(bo[bin]), n = static_cast<int>(bo[bin + 1]) - s0;
-  if (n <= 64 || n <= above || (CELLS && above == 0 && n > kBinSortMax)) continue;  // (CELLS: the segments beyond this launch's LDS are the next launch's)
+  if (n <= 64 || n <= above || (CELLS && above == 0 && n > kBinSortMax)) continue;
   __syncthreads();  // (sk is reused)
   unsigned long long* g = cb.keys + static_cast<size_t>(frame) * cb.Cpad + s0;
   const bool in_lds = n <= kBinSortMax;
